@@ -1,0 +1,14 @@
+"""decentralopf.jl_amd — MI355X-native ADMM consensus-OPF inner loop (hot path of
+rockstaedt/DecentralOPF.jl) behind the C ABI of include/dopf.h.
+
+The directory name contains a dot, so it is loaded through ``dopf_pkg.load()`` (repo root) under
+the module name ``decentralopf_jl_amd``.
+"""
+from . import _capi, network
+from ._capi import DopfError, Engine, default_params, hip_api
+from .network import (Generator, Line, Node, PackedProblem, Storage, calculate_ptdf, pack,
+                      three_node_case)
+
+__all__ = ["DopfError", "Engine", "default_params", "hip_api", "Generator", "Line", "Node",
+           "PackedProblem", "Storage", "calculate_ptdf", "pack", "three_node_case", "_capi",
+           "network"]

@@ -1,0 +1,274 @@
+"""ctypes binding of the C ABI declared in include/dopf.h.
+
+The product library is csrc/libdopf_hip.so (hand-written HIP for gfx950). There is NO CPU
+fallback: if the library is missing or HIP cannot start, loading raises.
+
+``CApi`` is generic over the symbol prefix because the CPU oracle (test infrastructure under
+oracle/) exports the same signatures prefixed ``oracle_``; only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg ever point it at that library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libdopf_hip.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class DopfProblem(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("L", C.c_int32), ("T", C.c_int32), ("G", C.c_int32), ("S", C.c_int32),
+        ("demand", c_double_p), ("ptdf", c_double_p), ("f_max", c_double_p),
+        ("gen_mc", c_double_p), ("gen_pmax", c_double_p), ("gen_node", c_int32_p),
+        ("sto_mc", c_double_p), ("sto_pmax", c_double_p), ("sto_emax", c_double_p),
+        ("sto_node", c_int32_p),
+    ]
+
+
+class DopfParams(C.Structure):
+    _fields_ = [
+        ("gamma", C.c_double), ("w_flow", C.c_double), ("w_prox", C.c_double),
+        ("eps", C.c_double), ("mask_thr", C.c_double),
+        ("max_iters", C.c_int32), ("n_agents_global", C.c_int32),
+        ("device", C.c_int32), ("flags", C.c_int32),
+        ("stream", C.c_void_p),
+    ]
+
+
+F_NO_GRAPH = 1
+F_SERIAL_AGENTS = 2
+
+
+class DopfError(RuntimeError):
+    pass
+
+
+def _f64(a, n=None) -> np.ndarray:
+    arr = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+    if n is not None and arr.size != n:
+        raise ValueError(f"expected {n} doubles, got {arr.size}")
+    return arr
+
+
+def _i32(a, n=None) -> np.ndarray:
+    arr = np.ascontiguousarray(np.asarray(a, dtype=np.int32).reshape(-1))
+    if n is not None and arr.size != n:
+        raise ValueError(f"expected {n} int32, got {arr.size}")
+    return arr
+
+
+def _dp(arr: Optional[np.ndarray]):
+    return None if arr is None else arr.ctypes.data_as(c_double_p)
+
+
+class CApi:
+    """One loaded shared library exporting <prefix>create/iterate/... (include/dopf.h)."""
+
+    def __init__(self, path: str, prefix: str = "dopf_"):
+        if not os.path.exists(path):
+            raise DopfError(
+                f"{path} not found: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "There is no CPU fallback for the HIP path.")
+        self.path = path
+        self.prefix = prefix
+        self.lib = C.CDLL(path)
+        p = prefix
+        L = self.lib
+        ctxp = C.c_void_p
+        self.has_mode = prefix != "dopf_"
+        create = getattr(L, p + "create")
+        create.restype = C.c_int
+        create.argtypes = [C.POINTER(ctxp), C.POINTER(DopfProblem), C.POINTER(DopfParams)] + (
+            [C.c_int32] if self.has_mode else [])
+        self._create = create
+        self._sig("destroy", None, [ctxp])
+        self._sig("last_error", C.c_char_p, [ctxp])
+        self._sig("iterate", C.c_int, [ctxp, C.c_int32, c_int32_p, c_int32_p])
+        self._sig("local_update", C.c_int, [ctxp])
+        self._sig("apply_consensus", C.c_int, [ctxp])
+        self._sig("consensus_size", C.c_int64, [ctxp])
+        self._sig("consensus_ptr", C.c_void_p, [ctxp])
+        self._sig("sync", C.c_int, [ctxp, c_int32_p, c_int32_p])
+        self._sig("get_duals", C.c_int, [ctxp, c_double_p, c_double_p, c_double_p])
+        self._sig("get_duals_used", C.c_int, [ctxp, c_double_p, c_double_p, c_double_p])
+        self._sig("get_primal", C.c_int, [ctxp, c_double_p, c_double_p, c_double_p, c_double_p])
+        self._sig("get_consensus", C.c_int, [ctxp, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p])
+        self._sig("get_residuals", C.c_int, [ctxp, c_double_p, c_double_p, c_double_p, c_int32_p])
+        self._sig("get_nodal_price", C.c_int, [ctxp, C.c_int32, c_double_p])
+        self._sig("set_state", C.c_int, [ctxp] + [c_double_p] * 8 + [C.c_int32])
+        if prefix == "dopf_":
+            self._sig("bind_consensus", C.c_int, [ctxp, C.c_void_p])
+            self._sig("solver_failures", C.c_int64, [ctxp])
+            self._sig("version", C.c_char_p, [])
+            self._sig("default_params", None, [C.POINTER(DopfParams)])
+
+    def _sig(self, name, restype, argtypes):
+        f = getattr(self.lib, self.prefix + name)
+        f.restype = restype
+        f.argtypes = argtypes
+        setattr(self, name, f)
+
+
+_hip_api: Optional[CApi] = None
+
+
+def hip_api() -> CApi:
+    """The product library. Raises (never falls back) if it is not built or cannot load."""
+    global _hip_api
+    if _hip_api is None:
+        _hip_api = CApi(HIP_LIB_PATH, "dopf_")
+    return _hip_api
+
+
+def default_params(**kw) -> DopfParams:
+    """The reference's literals: gamma 0.3, flow weight 10, prox 1,
+    eps 1e-3, mask threshold 1e-2."""
+    q = DopfParams(gamma=0.3, w_flow=10.0, w_prox=1.0, eps=1e-3, mask_thr=1e-2, max_iters=0,
+                   n_agents_global=0, device=-1, flags=0, stream=None)
+    for k, v in kw.items():
+        if not hasattr(q, k):
+            raise TypeError(f"unknown parameter {k}")
+        setattr(q, k, v)
+    return q
+
+
+class Engine:
+    """A context of the C ABI with numpy in/out. Mirrors include/dopf.h one to one."""
+
+    def __init__(self, api: CApi, *, N, L, T, demand, ptdf, f_max, gen_mc, gen_pmax, gen_node,
+                 sto_mc, sto_pmax, sto_emax, sto_node, params: Optional[DopfParams] = None,
+                 mode: Optional[int] = None):
+        self.api = api
+        self.N, self.L, self.T = int(N), int(L), int(T)
+        gen_mc = _f64(gen_mc)
+        sto_mc = _f64(sto_mc)
+        self.G, self.S = gen_mc.size, sto_mc.size
+        keep = dict(
+            demand=_f64(demand, self.N * self.T), ptdf=_f64(ptdf, self.L * self.N),
+            f_max=_f64(f_max, self.L), gen_mc=gen_mc, gen_pmax=_f64(gen_pmax, self.G),
+            gen_node=_i32(gen_node, self.G), sto_mc=sto_mc, sto_pmax=_f64(sto_pmax, self.S),
+            sto_emax=_f64(sto_emax, self.S), sto_node=_i32(sto_node, self.S))
+        prob = DopfProblem(N=self.N, L=self.L, T=self.T, G=self.G, S=self.S)
+        for k, v in keep.items():
+            ptr = v.ctypes.data_as(c_int32_p if v.dtype == np.int32 else c_double_p)
+            setattr(prob, k, ptr)
+        self.params = params if params is not None else default_params()
+        self._ctx = C.c_void_p()
+        args = [C.byref(self._ctx), C.byref(prob), C.byref(self.params)]
+        if api.has_mode:
+            args.append(C.c_int32(0 if mode is None else mode))
+        rc = api._create(*args)
+        if rc != 0:
+            msg = api.last_error(None)
+            raise DopfError(f"{api.prefix}create failed ({rc}): {msg.decode() if msg else ''}")
+
+    # -- lifecycle -----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self.api.destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self.api.last_error(self._ctx)
+            raise DopfError(f"{self.api.prefix}* failed ({rc}): {msg.decode() if msg else ''}")
+
+    # -- iteration -----------------------------------------------------------------------------
+    def iterate(self, n_iters: int):
+        done, conv = C.c_int32(0), C.c_int32(0)
+        self._chk(self.api.iterate(self._ctx, int(n_iters), C.byref(done), C.byref(conv)))
+        return done.value, bool(conv.value)
+
+    def local_update(self):
+        self._chk(self.api.local_update(self._ctx))
+
+    def apply_consensus(self):
+        self._chk(self.api.apply_consensus(self._ctx))
+
+    def consensus_size(self) -> int:
+        return int(self.api.consensus_size(self._ctx))
+
+    def consensus_ptr(self) -> int:
+        return int(self.api.consensus_ptr(self._ctx) or 0)
+
+    def bind_consensus(self, device_ptr: int):
+        self._chk(self.api.bind_consensus(self._ctx, C.c_void_p(device_ptr)))
+
+    def sync(self):
+        it, conv = C.c_int32(0), C.c_int32(0)
+        self._chk(self.api.sync(self._ctx, C.byref(it), C.byref(conv)))
+        return it.value, bool(conv.value)
+
+    def solver_failures(self) -> int:
+        return int(self.api.solver_failures(self._ctx))
+
+    # -- getters -------------------------------------------------------------------------------
+    def _duals(self, fn):
+        lam = np.zeros(self.T)
+        mu = np.zeros(self.L * self.T)
+        rho = np.zeros(self.L * self.T)
+        self._chk(fn(self._ctx, _dp(lam), _dp(mu), _dp(rho)))
+        # Julia shapes: lambda (T), mu/rho (L, T) column-major
+        return lam, mu.reshape(self.T, self.L).T.copy(), rho.reshape(self.T, self.L).T.copy()
+
+    def get_duals(self):
+        return self._duals(self.api.get_duals)
+
+    def get_duals_used(self):
+        return self._duals(self.api.get_duals_used)
+
+    def get_primal(self):
+        """P (G,T), D, C, E (S,T)."""
+        P = np.zeros(self.G * self.T)
+        D = np.zeros(self.S * self.T)
+        Cc = np.zeros(self.S * self.T)
+        E = np.zeros(self.S * self.T)
+        self._chk(self.api.get_primal(self._ctx, _dp(P), _dp(D), _dp(Cc), _dp(E)))
+        return (P.reshape(self.G, self.T), D.reshape(self.S, self.T),
+                Cc.reshape(self.S, self.T), E.reshape(self.S, self.T))
+
+    def get_consensus(self):
+        """injection (N,T), avg_U, avg_K, line_utilization (L,T), total_costs."""
+        inj = np.zeros(self.N * self.T)
+        aU = np.zeros(self.L * self.T)
+        aK = np.zeros(self.L * self.T)
+        fl = np.zeros(self.L * self.T)
+        cost = C.c_double(0)
+        self._chk(self.api.get_consensus(self._ctx, _dp(inj), _dp(aU), _dp(aK), _dp(fl), C.byref(cost)))
+        r = lambda v, rows: v.reshape(self.T, rows).T.copy()
+        return r(inj, self.N), r(aU, self.L), r(aK, self.L), r(fl, self.L), cost.value
+
+    def get_residuals(self):
+        a, b, c, it = C.c_double(0), C.c_double(0), C.c_double(0), C.c_int32(0)
+        self._chk(self.api.get_residuals(self._ctx, C.byref(a), C.byref(b), C.byref(c), C.byref(it)))
+        return a.value, b.value, c.value, it.value
+
+    def get_nodal_price(self, which: int = 0):
+        out = np.zeros(self.N * self.T)
+        self._chk(self.api.get_nodal_price(self._ctx, int(which), _dp(out)))
+        return out.reshape(self.T, self.N).T.copy()
+
+    def set_state(self, *, P=None, D=None, C_=None, avg_U=None, avg_K=None, lam=None, mu=None,
+                  rho=None, iteration: int = 1):
+        """Matrices in Julia shape: P (G,T) etc. agent-major rows; avg_U/mu/rho (L,T)."""
+        def am(a, rows):  # (rows, T) -> [t + T*row]
+            return None if a is None else _f64(np.asarray(a, dtype=np.float64).reshape(rows, self.T))
+
+        def cm(a, rows):  # (rows, T) -> column-major [r + rows*t]
+            return None if a is None else _f64(np.asarray(a, dtype=np.float64).reshape(rows, self.T).T)
+        bufs = [am(P, self.G), am(D, self.S), am(C_, self.S), cm(avg_U, self.L), cm(avg_K, self.L),
+                None if lam is None else _f64(lam, self.T), cm(mu, self.L), cm(rho, self.L)]
+        self._chk(self.api.set_state(self._ctx, *[_dp(b) for b in bufs], int(iteration)))
