@@ -4,11 +4,11 @@ rockstaedt/DecentralOPF.jl) behind the C ABI of include/dopf.h.
 The directory name contains a dot, so it is loaded through ``dopf_pkg.load()`` (repo root) under
 the module name ``decentralopf_jl_amd``.
 """
-from . import _capi, network
+from . import _capi, network, synth
 from ._capi import DopfError, Engine, default_params, hip_api
 from .network import (Generator, Line, Node, PackedProblem, Storage, calculate_ptdf, pack,
                       three_node_case)
 
 __all__ = ["DopfError", "Engine", "default_params", "hip_api", "Generator", "Line", "Node",
            "PackedProblem", "Storage", "calculate_ptdf", "pack", "three_node_case", "_capi",
-           "network"]
+           "network", "synth"]

@@ -1,0 +1,394 @@
+// kernels_consensus.hip — everything between two x-updates (gfx950, fp64).
+//
+//   k_tables   per (n,t): breakpoint table of Psi_{n,t} (only L > 0)                 [DESIGN.md]
+//   k_slack    per (n,t): sum over the node's agents of the closed-form slacks U, K  (only L > 0)
+//              = `result.avg_U += result_unit.U` of Result(...), src/structures/results.jl:83-84
+//   k_reduce   per-item partials -> consensus vector [inj sums | sum U | sum K | cost]
+//              = the agent loop of Result(...), results.jl:72-106, in a fixed summation order
+//   k_dual     injection, avg_U/avg_K, line_utilization (results.jl:108-116); lambda/mu/rho steps with
+//              the slack mask (src/optimization/update_duals.jl:1-39); |dual change| inf-norms
+//   k_price    price[n,t] = lambda_t + sum_l ptdf[l,n] (mu - rho)[l,t] for the next x-update
+//              (src/optimization/subproblems.jl:67-74) and the stop test of check_convergence!
+//              (src/optimization/convergence.jl:1-31)
+//   k_derive_* rebuild the consensus state from a primal state handed in by dopf_set_state
+#include "dopf_internal.h"
+
+namespace dopf {
+
+__device__ __forceinline__ double dmax0(double a) { return a > 0.0 ? a : 0.0; }
+
+// deterministic block sum (256 threads), result broadcast to all threads
+__device__ __forceinline__ double block_sum256(double x, double *sh)
+{
+    const int tid = threadIdx.x;
+    __syncthreads();
+    sh[tid] = x;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// network part of Psi at offset dl for line l of node n (closed-form slacks inside)
+__device__ __forceinline__ double line_term(const DevView &v, int l, int t, double h, double dl)
+{
+    const double w2 = 2.0 * v.w_flow, g = v.gamma;
+    const double f = v.flow[l + v.L * t] + h * dl, F = v.fmax[l];
+    const double U = dmax0((g * v.avgU[l + v.L * t] - w2 * (f - F)) / (w2 + g));
+    const double K = dmax0((g * v.avgK[l + v.L * t] + w2 * (f + F)) / (w2 + g));
+    return w2 * h * ((f + U - F) - (K - f - F));
+}
+
+// ------------------------------------------------------------------------------------------------
+// breakpoint tables (L > 0): one block per (n,t)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tables(DevView v, int P2)
+{
+    if (v.st->halt) return;
+    extern __shared__ double shm[];
+    double *key = shm, *jmp = shm + P2, *red = shm + 2 * P2;     // red: 256 doubles
+    const int tid = threadIdx.x;
+    const size_t at = blockIdx.x;
+    const int N = v.N, L = v.L, M2 = v.M2;
+    const int n = (int)(at % N), t = (int)(at / N);
+    const double w2 = 2.0 * v.w_flow, g = v.gamma, act = g / (w2 + g);
+
+    double s0part = 0.0;
+    for (int i = tid; i < P2; i += 256) {
+        double kv = INFINITY, jv = 0.0;
+        if (i < M2) {
+            const int l = i >> 1;
+            const double h = v.ptdf[l + L * n];
+            if (h != 0.0) {
+                const double f = v.flow[l + L * t], F = v.fmax[l];
+                const double dj = w2 * h * h * (1.0 - act);
+                if ((i & 1) == 0) {          // U switches: active where h*dlt < ...
+                    kv = (g * v.avgU[l + L * t] / w2 - f + F) / h;
+                    jv = h > 0.0 ? dj : -dj;
+                    s0part += w2 * h * h * (1.0 + act);     // at -inf exactly one of U, K is active
+                } else {                     // K switches
+                    kv = (-g * v.avgK[l + L * t] / w2 - f - F) / h;
+                    jv = h > 0.0 ? -dj : dj;
+                }
+            }
+        }
+        key[i] = kv;
+        jmp[i] = jv;
+    }
+    __syncthreads();
+    // bitonic sort ascending on key, payload jmp
+    for (int k2 = 2; k2 <= P2; k2 <<= 1) {
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (int i = tid; i < P2; i += 256) {
+                const int ixj = i ^ j2;
+                if (ixj > i) {
+                    const bool up = (i & k2) == 0;
+                    const double a = key[i], b = key[ixj];
+                    if ((a > b) == up) {
+                        key[i] = b; key[ixj] = a;
+                        const double ja = jmp[i]; jmp[i] = jmp[ixj]; jmp[ixj] = ja;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const double slope0 = g + block_sum256(s0part, red);
+    // number of finite kinks
+    __shared__ int m_sh;
+    if (tid == 0) m_sh = 0;
+    __syncthreads();
+    for (int i = tid; i < P2; i += 256)
+        if (key[i] < INFINITY && (i + 1 == P2 || !(key[i + 1] < INFINITY))) m_sh = i + 1;
+    __syncthreads();
+    const int m = m_sh;
+    // Psi at the first kink and at 0, by direct evaluation
+    const double b0 = m > 0 ? key[0] : 0.0;
+    double pa = 0.0, pz = 0.0;
+    for (int l = tid; l < L; l += 256) {
+        const double h = v.ptdf[l + L * n];
+        if (h != 0.0) { pa += line_term(v, l, t, h, b0); pz += line_term(v, l, t, h, 0.0); }
+    }
+    const double base = v.price[n + N * t] + g * v.s[t];
+    const double psiA = base + g * b0 + block_sum256(pa, red);
+    const double psiZ = base + block_sum256(pz, red);
+    double *ob = v.tb_beta + at * M2, *op = v.tb_psi + at * M2, *os = v.tb_slope + at * (M2 + 1);
+    if (tid == 0) {
+        // serial prefix sums: slope on piece j, Psi at kink j
+        double sl = slope0, ps = psiA;
+        os[0] = sl;
+        for (int j = 0; j < m; ++j) {
+            if (j > 0) ps += sl * (key[j] - key[j - 1]);
+            ob[j] = key[j];
+            op[j] = ps;
+            sl += jmp[j];
+            os[j + 1] = sl;
+        }
+        v.tb_m[at] = m;
+        v.tb_psi0[at] = psiZ;
+    }
+}
+
+void launch_tables(const DevView &v, hipStream_t s)
+{
+    if (v.L == 0) return;
+    int P2 = 2;
+    while (P2 < v.M2) P2 <<= 1;
+    const size_t shm = (size_t)(2 * P2 + 256) * sizeof(double);
+    hipLaunchKernelGGL(k_tables, dim3(v.N * v.T), dim3(256), shm, s, v, P2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// slack sums (L > 0): one block per (n,t), threads <-> lines, agents staged through LDS
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_slack(DevView v)
+{
+    if (v.st->halt) return;
+    __shared__ double dl[256];
+    const int tid = threadIdx.x;
+    const size_t at = blockIdx.x;
+    const int N = v.N, L = v.L, T = v.T;
+    const int n = (int)(at % N), t = (int)(at / N);
+    const int gb = v.node_gen_beg[n], ng = v.node_gen_beg[n + 1] - gb;
+    const int sb = v.node_sto_beg[n], ns = v.node_sto_beg[n + 1] - sb;
+    const int na = ng + ns;
+    const double w2 = 2.0 * v.w_flow, g = v.gamma, inv = 1.0 / (w2 + g);
+    for (int lc = 0; lc < L; lc += 256) {
+        const int l = lc + tid;
+        double aU = 0.0, aK = 0.0, kap = 0.0, sU = 0.0, sK = 0.0;
+        if (l < L) {
+            const double h = v.ptdf[l + L * n], f = v.flow[l + L * t], F = v.fmax[l];
+            aU = (g * v.avgU[l + L * t] - w2 * (f - F)) * inv;
+            aK = (g * v.avgK[l + L * t] + w2 * (f + F)) * inv;
+            kap = w2 * h * inv;
+        }
+        for (int base = 0; base < na; base += 256) {
+            const int a = base + tid;
+            __syncthreads();
+            if (a < na) dl[tid] = a < ng ? v.dltG[(size_t)(gb + a) * T + t] : v.dltS[(size_t)(sb + a - ng) * T + t];
+            __syncthreads();
+            const int cnt = na - base < 256 ? na - base : 256;
+            if (l < L)
+                for (int j = 0; j < cnt; ++j) {
+                    const double d = dl[j];
+                    sU += dmax0(aU - kap * d);
+                    sK += dmax0(aK + kap * d);
+                }
+        }
+        if (l < L) {
+            v.part_U[at * L + l] = sU;
+            v.part_K[at * L + l] = sK;
+        }
+    }
+}
+
+void launch_slack(const DevView &v, hipStream_t s)
+{
+    if (v.L == 0) return;
+    hipLaunchKernelGGL(k_slack, dim3(v.N * v.T), dim3(256), 0, s, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// reduce: blocks [0,N) sum the item partials of one node; the rest sum part_U / part_K over nodes
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_reduce(DevView v)
+{
+    if (v.st->halt) return;
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    const int N = v.N, L = v.L, T = v.T;
+    if ((int)blockIdx.x < N) {
+        const int n = blockIdx.x;
+        const int TT = T < 256 ? T : 256, R = 256 / TT;
+        const int r = tid / TT, tt = tid - r * TT;
+        const int g0 = v.node_gitem_beg[n], g1 = v.node_gitem_beg[n + 1];
+        const int s0 = v.node_sitem_beg[n], s1 = v.node_sitem_beg[n + 1];
+        for (int tc = 0; tc < T; tc += TT) {
+            const int t = tc + tt;
+            double acc = 0.0;
+            if (r < R && t < T) {
+                for (int i = g0 + r; i < g1; i += R) acc += v.part_ginj[(size_t)i * T + t];
+                for (int i = s0 + r; i < s1; i += R) acc += v.part_sinj[(size_t)i * T + t];
+            }
+            __syncthreads();
+            red[tid] = acc;
+            __syncthreads();
+            if (r == 0 && t < T) {
+                double sum = 0.0;
+                for (int q = 0; q < R; ++q) sum += red[q * TT + tt];
+                v.cons[n + (size_t)N * t] = sum;
+            }
+        }
+        if (n == 0) {
+            double c = 0.0;
+            for (int i = tid; i < v.nGenItems; i += 256) c += v.part_gcost[i];
+            for (int i = tid; i < v.nStoItems; i += 256) c += v.part_scost[i];
+            c = block_sum256(c, red);
+            if (tid == 0) v.cons[(size_t)N * T + 2 * (size_t)L * T] = c;
+        }
+    } else {
+        const size_t LT = (size_t)L * T;
+        const size_t idx = (size_t)(blockIdx.x - N) * 256 + tid;
+        if (idx < 2 * LT) {
+            const int which = idx >= LT;
+            const size_t rem = idx - which * LT;            // l + L*t
+            const int l = (int)(rem % L), t = (int)(rem / L);
+            const double *src = which ? v.part_K : v.part_U;
+            double sum = 0.0;
+            for (int n = 0; n < N; ++n) sum += src[((size_t)n + (size_t)N * t) * L + l];
+            v.cons[(size_t)N * T + idx] = sum;
+        }
+    }
+}
+
+void launch_reduce(const DevView &v, hipStream_t s)
+{
+    const size_t LT2 = 2 * (size_t)v.L * v.T;
+    const int blocks = v.N + (int)((LT2 + 255) / 256);
+    hipLaunchKernelGGL(k_reduce, dim3(blocks), dim3(256), 0, s, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dual update
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_max_pos(unsigned long long *addr, double vpos)
+{
+    atomicMax(addr, (unsigned long long)__double_as_longlong(vpos));   // vpos >= 0: bit order = value order
+}
+
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void k_dual(DevView v)
+{
+    if (UPDATE && v.st->halt) return;
+    const int N = v.N, L = v.L, T = v.T;
+    const size_t NT = (size_t)N * T, LT = (size_t)L * T;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const double *cinj = v.cons, *cU = v.cons + NT, *cK = cU + LT;
+    double rl = 0.0, rm = 0.0, rr = 0.0;
+    if (i < NT) v.inj[i] = cinj[i] - v.demand[i];                         // results.jl:58-100
+    if (i < (size_t)T) {
+        const int t = (int)i;
+        double sum = 0.0;
+        for (int n = 0; n < N; ++n) sum += cinj[n + (size_t)N * t] - v.demand[n + (size_t)N * t];
+        v.s[t] = sum;
+        if (UPDATE) {
+            const double lo = v.lam[t], ln = lo + v.gamma * sum;          // update_duals.jl:8-13
+            v.lam_used[t] = lo;
+            v.lam[t] = ln;
+            rl = fabs(ln - lo);
+        }
+    }
+    if (i < LT) {
+        const int l = (int)(i % L), t = (int)(i / L);
+        double f = 0.0;
+        for (int n = 0; n < N; ++n) f += v.ptdf[l + (size_t)L * n] * (cinj[n + (size_t)N * t] - v.demand[n + (size_t)N * t]);
+        v.flow[i] = f;                                                    // results.jl:114
+        if (UPDATE) {
+            const double aU = v.invA * cU[i], aK = v.invA * cK[i];       // results.jl:108-112
+            v.avgU[i] = aU;
+            v.avgK[i] = aK;
+            const double mo = v.mu[i], ro = v.rho[i], F = v.fmax[l];
+            const double mn = (mo + v.gamma * (f + aU - F)) * (aU <= v.mask_thr ? 1.0 : 0.0);   // :18-25
+            const double rn = (ro + v.gamma * (aK - f - F)) * (aK <= v.mask_thr ? 1.0 : 0.0);   // :30-37
+            v.mu_used[i] = mo; v.rho_used[i] = ro;
+            v.mu[i] = mn; v.rho[i] = rn;
+            rm = fabs(mn - mo);
+            rr = fabs(rn - ro);
+        }
+    }
+    if (UPDATE) {
+        // wave max, then one atomic per wave (max is order independent: deterministic)
+        for (int d = 32; d > 0; d >>= 1) {
+            rl = fmax(rl, __shfl_xor(rl, d));
+            rm = fmax(rm, __shfl_xor(rm, d));
+            rr = fmax(rr, __shfl_xor(rr, d));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (rl > 0.0) atomic_max_pos(&v.st->resbits[0], rl);
+            if (rm > 0.0) atomic_max_pos(&v.st->resbits[1], rm);
+            if (rr > 0.0) atomic_max_pos(&v.st->resbits[2], rr);
+        }
+        if (i == 0) v.st->total_cost = v.cons[NT + 2 * LT];
+    }
+}
+
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void k_price(DevView v)
+{
+    const int N = v.N, L = v.L;
+    const size_t NT = (size_t)N * v.T;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // recomputed even after a halt: the duals are frozen then, so the values are identical
+    if (i < NT) {
+        const int n = (int)(i % N), t = (int)(i / N);
+        double p = v.lam[t];
+        for (int l = 0; l < L; ++l) p += v.ptdf[l + (size_t)L * n] * (v.mu[l + (size_t)L * t] - v.rho[l + (size_t)L * t]);
+        v.price[i] = p;
+    }
+    if (UPDATE && i == 0) {
+        Status *st = v.st;
+        if (st->halt) return;
+        if (st->iteration != 1) {                                         // convergence.jl:3
+            double r0 = __longlong_as_double((long long)st->resbits[0]);
+            double r1 = __longlong_as_double((long long)st->resbits[1]);
+            double r2 = __longlong_as_double((long long)st->resbits[2]);
+            st->res[0] = r0; st->res[1] = r1; st->res[2] = r2;
+            st->converged = (r0 < v.eps) && (r1 < v.eps) && (r2 < v.eps);
+        }
+        st->resbits[0] = st->resbits[1] = st->resbits[2] = 0ull;
+        st->iters_total += 1;
+        if (!st->converged) st->iteration += 1;                           // convergence.jl:25-30
+        st->halt = st->converged || (v.max_iters > 0 && st->iteration > v.max_iters);
+    }
+}
+
+void launch_dual(const DevView &v, hipStream_t s)
+{
+    const size_t NT = (size_t)v.N * v.T, LT = (size_t)v.L * v.T;
+    const size_t n1 = NT > LT ? NT : LT;
+    hipLaunchKernelGGL(k_dual<true>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, v);
+    hipLaunchKernelGGL(k_price<true>, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// set_state support: consensus sums straight from the primal arrays (slow path, not on the hot loop)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_derive_cons(DevView v)
+{
+    const int N = v.N, T = v.T;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)N * T) return;
+    const int n = (int)(i % N), t = (int)(i / N);
+    double sum = 0.0;
+    for (int g = v.node_gen_beg[n]; g < v.node_gen_beg[n + 1]; ++g) sum += v.P[(size_t)g * T + t];
+    for (int s = v.node_sto_beg[n]; s < v.node_sto_beg[n + 1]; ++s) sum += v.D[(size_t)s * T + t] - v.C[(size_t)s * T + t];
+    v.cons[i] = sum;
+}
+
+__global__ __launch_bounds__(256) void k_derive_level(DevView v)
+{
+    const int T = v.T;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= v.S) return;
+    double e = 0.0;
+    for (int t = 0; t < T; ++t) {
+        e += v.C[(size_t)s * T + t] - v.D[(size_t)s * T + t];
+        v.E[(size_t)s * T + t] = e;
+    }
+}
+
+void launch_derive(const DevView &v, hipStream_t s)
+{
+    const size_t NT = (size_t)v.N * v.T, LT = (size_t)v.L * v.T;
+    const size_t n1 = NT > LT ? NT : LT;
+    hipLaunchKernelGGL(k_derive_cons, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, v);
+    if (v.S > 0) hipLaunchKernelGGL(k_derive_level, dim3((unsigned)((v.S + 255) / 256)), dim3(256), 0, s, v);
+    hipLaunchKernelGGL(k_dual<false>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, v);
+    hipLaunchKernelGGL(k_price<false>, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, v);
+}
+
+}  // namespace dopf

@@ -79,10 +79,10 @@ static int lu_factor(int n, double *a, int *piv)
 
 static void lu_solve(int n, const double *a, const int *piv, double *x)
 {
-    for (int k = 0; k < n; ++k) {
+    for (int k = 0; k < n; ++k)
         if (piv[k] != k) { double tmp = x[k]; x[k] = x[piv[k]]; x[piv[k]] = tmp; }
+    for (int k = 0; k < n; ++k)
         for (int i = k + 1; i < n; ++i) x[i] -= a[i * n + k] * x[k];
-    }
     for (int i = n - 1; i >= 0; --i) {
         double v = x[i];
         for (int j = i + 1; j < n; ++j) v -= a[i * n + j] * x[j];
@@ -240,9 +240,8 @@ int oracle_qp_solve(int32_t n, int32_t m, const double *Q, const double *c0, con
                 for (int i = 0; i < n; ++i) {
                     x[i] += al * dx[i];
                     z[i] += al * dz[i];
-                    if (bounded[i]) { t[i] = u[i] - x[i]; s[i] += al * ds[i];
-                        if (t[i] <= 0) t[i] = 1e-300; }
-                    if (x[i] <= 0) x[i] = 1e-300;
+                    /* t is stepped on its own (t = u - x would cancel once t << u) */
+                    if (bounded[i]) { t[i] -= al * dx[i]; s[i] += al * ds[i]; }
                 }
                 for (int r = 0; r < m; ++r) y[r] += al * dy[r];
             }
