@@ -108,6 +108,12 @@ class CApi:
             self._sig("solver_failures", C.c_int64, [ctxp])
             self._sig("version", C.c_char_p, [])
             self._sig("default_params", None, [C.POINTER(DopfParams)])
+        else:   # oracle-only entry points (tests)
+            self._sig("set_threads", None, [ctxp, C.c_int32])
+            self._sig("get_agent_slacks", C.c_int, [ctxp, C.c_int32, c_double_p, c_double_p])
+            self._sig("calculate_ptdf", C.c_int, [C.c_int32, C.c_int32, c_int32_p, c_int32_p, c_double_p,
+                                                  C.c_int32, c_double_p])
+            self._sig("qp_solve", C.c_int, [C.c_int32, C.c_int32] + [c_double_p] * 8 + [c_int32_p])
 
     def _sig(self, name, restype, argtypes):
         f = getattr(self.lib, self.prefix + name)
@@ -214,6 +220,9 @@ class Engine:
 
     def solver_failures(self) -> int:
         return int(self.api.solver_failures(self._ctx))
+
+    def set_threads(self, n: int):
+        self.api.set_threads(self._ctx, int(n))
 
     # -- getters -------------------------------------------------------------------------------
     def _duals(self, fn):

@@ -538,6 +538,22 @@ int dopf_set_state(dopf_ctx *c, const double *P, const double *D, const double *
     return DOPF_OK;
 }
 
+// diagnostics: the breakpoint table of Psi_{n,t} as the last x-update saw it (L > 0 only)
+int dopf_debug_table(dopf_ctx *c, int32_t n, int32_t t, double *beta, double *psi, double *slope, double *psi0, int32_t *m)
+{
+    if (!c || c->v.L == 0 || n < 0 || n >= c->v.N || t < 0 || t >= c->v.T) return DOPF_E_INVALID;
+    DeviceGuard guard(c->device);
+    const DevView &v = c->v;
+    const size_t at = (size_t)n + (size_t)v.N * t;
+    HIPCHK(c, hipStreamSynchronize(c->main));
+    HIPCHK(c, hipMemcpy(beta, v.tb_beta + at * v.M2, sizeof(double) * v.M2, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(psi, v.tb_psi + at * v.M2, sizeof(double) * v.M2, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(slope, v.tb_slope + at * (v.M2 + 1), sizeof(double) * (v.M2 + 1), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(psi0, v.tb_psi0 + at, sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(m, v.tb_m + at, sizeof(int), hipMemcpyDeviceToHost));
+    return DOPF_OK;
+}
+
 int64_t dopf_solver_failures(dopf_ctx *c)
 {
     if (!c) return -1;

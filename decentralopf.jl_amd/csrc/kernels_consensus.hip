@@ -106,27 +106,36 @@ __global__ __launch_bounds__(256) void k_tables(DevView v, int P2)
         if (key[i] < INFINITY && (i + 1 == P2 || !(key[i + 1] < INFINITY))) m_sh = i + 1;
     __syncthreads();
     const int m = m_sh;
-    // Psi at the first kink and at 0, by direct evaluation
-    const double b0 = m > 0 ? key[0] : 0.0;
-    double pa = 0.0, pz = 0.0;
+    // Psi(0) by direct evaluation; the kinks are then reached by walking the pieces outwards from 0.
+    // (Anchoring at 0 keeps full precision where the agents' steps live, |dlt| <= pmax, even when a
+    // numerically tiny PTDF entry throws a kink out to 1e19.)
+    double pz = 0.0;
     for (int l = tid; l < L; l += 256) {
         const double h = v.ptdf[l + L * n];
-        if (h != 0.0) { pa += line_term(v, l, t, h, b0); pz += line_term(v, l, t, h, 0.0); }
+        if (h != 0.0) pz += line_term(v, l, t, h, 0.0);
     }
-    const double base = v.price[n + N * t] + g * v.s[t];
-    const double psiA = base + g * b0 + block_sum256(pa, red);
-    const double psiZ = base + block_sum256(pz, red);
+    const double psiZ = v.price[n + N * t] + g * v.s[t] + block_sum256(pz, red);
     double *ob = v.tb_beta + at * M2, *op = v.tb_psi + at * M2, *os = v.tb_slope + at * (M2 + 1);
     if (tid == 0) {
-        // serial prefix sums: slope on piece j, Psi at kink j
-        double sl = slope0, ps = psiA;
+        double sl = slope0;
         os[0] = sl;
+        int j0 = m;                                   // first kink >= 0
         for (int j = 0; j < m; ++j) {
-            if (j > 0) ps += sl * (key[j] - key[j - 1]);
             ob[j] = key[j];
-            op[j] = ps;
+            if (j0 == m && key[j] >= 0.0) j0 = j;
             sl += jmp[j];
-            os[j + 1] = sl;
+            os[j + 1] = sl;                           // slope on piece j+1 = (kink j, kink j+1)
+        }
+        // 0 lies on piece j0
+        if (j0 < m) {
+            double ps = psiZ + os[j0] * key[j0];
+            op[j0] = ps;
+            for (int j = j0 + 1; j < m; ++j) { ps += os[j] * (key[j] - key[j - 1]); op[j] = ps; }
+        }
+        if (j0 > 0) {
+            double ps = psiZ + os[j0] * key[j0 - 1];
+            op[j0 - 1] = ps;
+            for (int j = j0 - 2; j >= 0; --j) { ps -= os[j + 1] * (key[j + 1] - key[j]); op[j] = ps; }
         }
         v.tb_m[at] = m;
         v.tb_psi0[at] = psiZ;

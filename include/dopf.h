@@ -148,6 +148,10 @@ int dopf_set_state(dopf_ctx *ctx, const double *P, const double *D, const double
 /* Diagnostics: number of storage sub-problems whose inner root search hit its iteration cap
  * since creation (0 in every healthy run), and a version string. */
 int64_t dopf_solver_failures(dopf_ctx *ctx);
+/* Diagnostics (L > 0): the breakpoint table of node n, timestep t that the last x-update used:
+ * beta, psi: 2L doubles (first *m valid, ascending), slope: 2L+1, psi0 = Psi(0). */
+int dopf_debug_table(dopf_ctx *ctx, int32_t n, int32_t t, double *beta, double *psi, double *slope,
+                     double *psi0, int32_t *m);
 const char *dopf_version(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,69 @@
+"""Central multi-period DC-OPF as one LP (test utility, CPU, SciPy/HiGHS).
+
+Restates src/opf_central_reference.jl:21-53 of the reference (variables P, D, C, E, U, K; energy
+balance per timestep; flow limits in slack-equality form; storage balance) to produce the parity
+target "converged objective within 1e-3 of the central optimum" for synthetic cases, where no
+Gurobi answer exists. Three-node optimum: 14035 (thesis Tables 8-16).
+"""
+import numpy as np
+from scipy import sparse
+from scipy.optimize import linprog
+
+
+def solve_central(pp):
+    N, L, T, G, S = pp.N, pp.L, pp.T, pp.G, pp.S
+    nP, nS = G * T, S * T
+    # variable order: P[g,t] | D[s,t] | C[s,t] | E[s,t]  (U, K eliminated: |flow| <= f_max)
+    iP = lambda g, t: g * T + t
+    iD = lambda s, t: nP + s * T + t
+    iC = lambda s, t: nP + nS + s * T + t
+    iE = lambda s, t: nP + 2 * nS + s * T + t
+    nv = nP + 3 * nS
+    c = np.zeros(nv)
+    c[:nP] = np.repeat(pp.gen_mc, T)
+    c[nP:nP + nS] = np.repeat(pp.sto_mc, T)
+    c[nP + nS:nP + 2 * nS] = np.repeat(pp.sto_mc, T)
+    ub = np.concatenate([np.repeat(pp.gen_pmax, T), np.repeat(pp.sto_pmax, T), np.repeat(pp.sto_pmax, T),
+                         np.repeat(pp.sto_emax, T)])
+    rows, cols, vals, beq = [], [], [], []
+    r = 0
+    for t in range(T):                                   # EB[t]: sum of injections = 0
+        for g in range(G):
+            rows.append(r); cols.append(iP(g, t)); vals.append(1.0)
+        for s in range(S):
+            rows += [r, r]; cols += [iD(s, t), iC(s, t)]; vals += [1.0, -1.0]
+        beq.append(pp.demand[:, t].sum())
+        r += 1
+    for s in range(S):                                   # E[t] = E[t-1] - D + C
+        for t in range(T):
+            rows += [r, r, r]; cols += [iE(s, t), iD(s, t), iC(s, t)]; vals += [1.0, 1.0, -1.0]
+            if t > 0:
+                rows.append(r); cols.append(iE(s, t - 1)); vals.append(-1.0)
+            beq.append(0.0)
+            r += 1
+    Aeq = sparse.csr_matrix((vals, (rows, cols)), shape=(r, nv))
+    Aub = bub = None
+    if L > 0:                                            # -f_max <= ptdf * I <= f_max
+        rows, cols, vals, bub = [], [], [], []
+        r = 0
+        for sign in (1.0, -1.0):
+            for t in range(T):
+                for l in range(L):
+                    for g in range(G):
+                        h = pp.ptdf[l, pp.gen_node[g]]
+                        if h != 0.0:
+                            rows.append(r); cols.append(iP(g, t)); vals.append(sign * h)
+                    for s in range(S):
+                        h = pp.ptdf[l, pp.sto_node[s]]
+                        if h != 0.0:
+                            rows += [r, r]; cols += [iD(s, t), iC(s, t)]; vals += [sign * h, -sign * h]
+                    bub.append(pp.f_max[l] + sign * float(pp.ptdf[l, :] @ pp.demand[:, t]))
+                    r += 1
+        Aub = sparse.csr_matrix((vals, (rows, cols)), shape=(r, nv))
+    res = linprog(c, A_ub=Aub, b_ub=bub, A_eq=Aeq, b_eq=beq, bounds=list(zip(np.zeros(nv), ub)), method="highs")
+    if res.status != 0:
+        raise RuntimeError(res.message)
+    x = res.x
+    return dict(objective=res.fun, P=x[:nP].reshape(G, T), D=x[nP:nP + nS].reshape(S, T),
+                C=x[nP + nS:nP + 2 * nS].reshape(S, T), E=x[nP + 2 * nS:].reshape(S, T),
+                lam=res.eqlin.marginals[:T])

@@ -1,0 +1,222 @@
+"""Parity of the HIP path (libdopf_hip.so, through the C ABI) against the oracle, the reference's
+golden dumps and size-independent optimality properties. Needs a real MI355X: pytest -m gpu."""
+import numpy as np
+import pytest
+
+from central_lp import solve_central
+from decentralopf_jl_amd import _capi, synth
+from helpers import follow_golden, make_engine, max_diff, state_of, storage_kkt_violation
+
+pytestmark = pytest.mark.gpu
+
+CASES = {"TNS": dict(), "big_gamma": dict(gamma=0.5), "wrong_weight": dict(w_flow=0.15)}
+
+
+# ---- the reference's own data ---------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_hip_follows_reference_dump(hip_api, three_node, golden, name):
+    e = make_engine(hip_api, three_node[4], eps=0.0, **CASES[name])
+    follow_golden(e, golden[name], atol_primal=1e-5, atol_dual=1e-5)      # Gurobi noise floor ~6e-6
+    assert e.solver_failures() == 0
+
+
+@pytest.mark.parametrize("flags", [0, _capi.F_NO_GRAPH, _capi.F_SERIAL_AGENTS], ids=["graph", "eager", "one-stream"])
+def test_hip_three_node_converges_like_the_thesis(hip_api, three_node, thesis, flags):
+    e = make_engine(hip_api, three_node[4], flags=flags)
+    done, conv = e.iterate(5000)                                          # one call, stop test on the device
+    lam_res, mu_res, rho_res, it = e.get_residuals()
+    assert conv and done == 476 and it == 476 and max(lam_res, mu_res, rho_res) < 1e-3
+    P, D, C, E = e.get_primal()
+    inj, aU, aK, flow, cost = e.get_consensus()
+    t, c = thesis["admm"], thesis["central"]
+    assert np.abs(P - np.asarray(t["P"])).max() < 6e-5
+    assert np.abs(flow - np.asarray(t["flows"])).max() < 6e-5
+    assert abs(cost - c["objective"]) / c["objective"] < 1e-3             # north-star tolerance
+    assert np.abs(P - np.asarray(c["P"])).max() / 220 < 2e-3              # per-mille table match
+    assert np.abs(e.get_nodal_price(0) - np.asarray(t["nodal_price"])).max() < 6e-5
+    assert e.iterate(10) == (0, True)                                     # frozen after convergence
+
+
+@pytest.mark.parametrize("name", ["big_gamma", "wrong_weight"])
+def test_hip_negative_controls(hip_api, three_node, name):
+    e = make_engine(hip_api, three_node[4], max_iters=750, **CASES[name])
+    done, conv = e.iterate(2000)
+    assert not conv and done == 750 and e.get_residuals()[3] == 751
+
+
+# ---- against the oracle on seeded synthetic cases ----------------------------------------------------
+
+SYNTH = [
+    # name, case, params, oracle mode, iterations, tolerance (fp64; 1e-9 on copper plate)
+    ("three-node-literal", None, dict(), 0, 60, 1e-7),
+    ("copper-T1", dict(n_gen=9, n_sto=4, T=1, seed=9), dict(gamma=0.05), 1, 20, 1e-9),
+    ("copper-T6", dict(n_gen=20, n_sto=5, T=6), dict(gamma=0.05), 1, 40, 1e-9),
+    ("copper-T24-lps8", dict(n_gen=100, n_sto=30, T=24, seed=2), dict(gamma=0.01), 1, 40, 1e-9),
+    ("copper-T40-lps16", dict(n_gen=50, n_sto=20, T=40, seed=5), dict(gamma=0.02), 1, 15, 1e-9),
+    ("copper-T96-lps32", dict(n_gen=50, n_sto=20, T=96, seed=3), dict(gamma=0.02), 1, 15, 1e-9),
+    ("copper-T168-lps64", dict(n_gen=50, n_sto=20, T=168, seed=4), dict(gamma=0.02), 1, 8, 1e-9),
+    ("copper-T250-nch4", dict(n_gen=20, n_sto=6, T=250, seed=6), dict(gamma=0.02), 1, 4, 1e-9),
+    ("copper-T400-nch8", dict(n_gen=20, n_sto=6, T=400, seed=7), dict(gamma=0.02), 1, 3, 1e-9),
+    ("copper-T600-gen-only", dict(n_gen=30, n_sto=0, T=600, seed=8), dict(gamma=0.02), 1, 5, 1e-9),
+    ("copper-gamma1-diverging", dict(n_gen=60, n_sto=12, T=24, seed=12), dict(gamma=1.0), 1, 25, 1e-7),
+    ("copper-multinode", dict(n_gen=40, n_sto=10, T=12, N=5, seed=13), dict(gamma=0.02), 1, 20, 1e-9),
+    ("net-4x5", dict(n_gen=12, n_sto=4, T=5, N=4, L=5, seed=5, fmax_factor=0.7, fmax_min=5), dict(gamma=0.1), 1, 40, 1e-8),
+    ("net-4x5-literal", dict(n_gen=12, n_sto=4, T=5, N=4, L=5, seed=5, fmax_factor=0.7, fmax_min=5), dict(gamma=0.1), 0, 15, 1e-6),
+    ("net-6x9", dict(n_gen=60, n_sto=15, T=24, N=6, L=9, seed=7, fmax_factor=0.6, fmax_min=5), dict(gamma=0.05), 1, 30, 1e-8),
+    ("net-30x50-empty-nodes", dict(n_gen=25, n_sto=6, T=8, N=30, L=50, seed=17, fmax_factor=0.6, fmax_min=5), dict(gamma=0.05), 1, 10, 1e-8),
+    ("storages-only", dict(n_gen=0, n_sto=12, T=24, seed=14), dict(gamma=0.05), 1, 10, 1e-9),
+]
+
+
+@pytest.mark.parametrize("name,case,params,mode,iters,tol", SYNTH, ids=[s[0] for s in SYNTH])
+def test_hip_one_step_parity(hip_api, oracle_api, three_node, name, case, params, mode, iters, tol):
+    """Both sides start every iteration from the SAME state (the oracle's), so the number checked is
+    the error of one x-update + consensus + dual update, not its amplification by the dynamics."""
+    pp = three_node[4] if case is None else synth.synthetic_case(**case)
+    h = make_engine(hip_api, pp, eps=0.0, **params)
+    o = make_engine(oracle_api, pp, mode=mode, eps=0.0, **params)
+    for k in range(iters):
+        h.iterate(1)
+        o.iterate(1)
+        sh, so = state_of(h), state_of(o)
+        scale = max(1.0, float(np.abs(so["lam"]).max()))
+        worst, where = max_diff(sh, so, keys=[x for x in sh if x != "cost"])
+        assert worst <= tol * scale, (k, where, worst)
+        assert abs(sh["cost"][0] - so["cost"][0]) <= 1e-9 * max(1.0, abs(so["cost"][0]))
+        h.set_state(P=so["P"], D=so["D"], C_=so["C"], avg_U=so["avg_U"], avg_K=so["avg_K"], lam=so["lam"],
+                    mu=so["mu"], rho=so["rho"], iteration=o.get_residuals()[3])
+    assert h.solver_failures() == 0
+
+
+def test_hip_free_running_trajectory(hip_api, oracle_api):
+    """No state resets: 200 iterations side by side on a convergent case stay within 1e-8."""
+    pp = synth.synthetic_case(100, 10, 24)
+    g = 1.0 / (pp.G + pp.S)
+    h = make_engine(hip_api, pp, eps=0.0, gamma=g)
+    o = make_engine(oracle_api, pp, mode=1, eps=0.0, gamma=g)
+    h.iterate(200)
+    o.iterate(200)
+    assert max_diff(state_of(h), state_of(o), keys=["P", "D", "C", "E", "lam", "inj"])[0] < 1e-8
+
+
+def test_hip_edge_cases(hip_api, oracle_api):
+    pp = synth.synthetic_case(8, 4, 6, seed=10)
+    pp.sto_pmax[0] = 0.0          # cannot move
+    pp.sto_emax[1] = 0.0          # cannot store
+    pp.gen_pmax[2] = 0.0          # cannot produce
+    h = make_engine(hip_api, pp, eps=0.0, gamma=0.05)
+    o = make_engine(oracle_api, pp, mode=1, eps=0.0, gamma=0.05)
+    h.iterate(15)
+    o.iterate(15)
+    sh, so = state_of(h), state_of(o)
+    assert max_diff(sh, so)[0] < 1e-8
+    assert np.abs(sh["D"][0]).max() == 0 and np.abs(sh["C"][0]).max() == 0 and np.abs(sh["P"][2]).max() == 0
+    assert np.abs(sh["E"][1]).max() < 1e-9
+
+
+def test_hip_rejects_bad_input(hip_api):
+    pp = synth.synthetic_case(4, 2, 3)
+    kw = pp.engine_kwargs()
+    kw["gen_node"] = np.asarray([0, 0, 5, 0], dtype=np.int32)
+    with pytest.raises(_capi.DopfError, match="gen_node"):
+        _capi.Engine(hip_api, params=_capi.default_params(), **kw)
+    with pytest.raises(_capi.DopfError, match="T <= 512"):
+        make_engine(hip_api, synth.synthetic_case(4, 2, 600))
+    with pytest.raises(_capi.DopfError, match="positive"):
+        make_engine(hip_api, pp, gamma=0.0)
+
+
+def test_hip_is_bitwise_reproducible(hip_api):
+    """Fixed-order reductions: two runs give identical bits, with and without the graph."""
+    pp = synth.synthetic_case(3000, 300, 24, seed=31)
+    outs = []
+    for flags in (0, 0, _capi.F_NO_GRAPH, _capi.F_SERIAL_AGENTS):
+        e = make_engine(hip_api, pp, eps=0.0, gamma=1.0 / 3300, flags=flags)
+        e.iterate(40)
+        outs.append(state_of(e))
+    for o in outs[1:]:
+        for k in outs[0]:
+            assert np.array_equal(outs[0][k], o[k]), k
+
+
+def test_hip_sharded_contexts_equal_one(hip_api):
+    """Two contexts on one GPU, consensus buffers summed by hand: the N > 1 arithmetic without RCCL."""
+    import torch
+    pp = synth.synthetic_case(300, 40, 24, N=3, L=3, seed=4, fmax_factor=0.8, fmax_min=5)
+    A = pp.G + pp.S
+    ref = make_engine(hip_api, pp, eps=0.0, gamma=0.01)
+    ref.iterate(12)
+    want = state_of(ref)
+    engs = [make_engine(hip_api, pp.shard(r, 2), eps=0.0, gamma=0.01, n_agents_global=A) for r in range(2)]
+    bufs = [torch.zeros(e.consensus_size(), dtype=torch.float64, device="cuda") for e in engs]
+    for e, b in zip(engs, bufs):
+        e.bind_consensus(b.data_ptr())
+    for _ in range(12):
+        for e in engs:
+            e.local_update()
+        for e in engs:
+            e.sync()
+        total = bufs[0] + bufs[1]
+        bufs[0].copy_(total)
+        bufs[1].copy_(total)
+        torch.cuda.synchronize()
+        for e in engs:
+            e.apply_consensus()
+        for e in engs:
+            e.sync()
+    got = [state_of(e) for e in engs]
+    for k in ("lam", "mu", "rho", "inj", "avg_U", "avg_K", "flow", "cost"):
+        for g in got:
+            assert np.abs(g[k] - want[k]).max() <= 1e-9 * max(1.0, np.abs(want[k]).max()), k
+    assert np.abs(np.concatenate([g["P"] for g in got]) - want["P"]).max() < 1e-9
+
+
+# ---- BASELINE.json's full sizes: size-independent properties -----------------------------------------
+
+FULL = [("config1-1100x24", 1, 1.0), ("config2-50k-x96", 2, 1.0), ("config4-1M-x24", 4, 1.0)]
+
+
+@pytest.mark.parametrize("name,idx,scale", FULL, ids=[f[0] for f in FULL])
+def test_hip_full_size_properties(hip_api, name, idx, scale):
+    pp = synth.baseline_config(idx, scale=scale)
+    A = pp.G + pp.S
+    gamma = 1.0 / A
+    e = make_engine(hip_api, pp, eps=0.0, gamma=gamma)
+    e.iterate(30)
+    before = state_of(e)
+    e.iterate(1)
+    after = state_of(e)
+    lam_used = e.get_duals_used()[0]
+    s_prev = before["inj"].sum(axis=0)
+    # generators: closed form of SURVEY.md section 9.4, vectorised over all (g,t)
+    want = np.clip(before["P"] - (pp.gen_mc[:, None] + lam_used[None, :] + gamma * s_prev[None, :]) / (1 + gamma),
+                   0.0, pp.gen_pmax[:, None])
+    assert np.abs(after["P"] - want).max() < 1e-9
+    # storages: bounds, level recursion, and the KKT optimality certificate for every storage
+    D, C, E = after["D"], after["C"], after["E"]
+    assert D.min() >= 0 and C.min() >= 0 and (D - pp.sto_pmax[:, None]).max() <= 0 and (C - pp.sto_pmax[:, None]).max() <= 0
+    assert E.min() >= -1e-9 and (E - pp.sto_emax[:, None]).max() <= 1e-9
+    assert np.abs(np.cumsum(C - D, axis=1) - E).max() < 1e-9
+    theta = lam_used[None, :] + gamma * (s_prev[None, :] - (before["D"] - before["C"]))
+    assert storage_kkt_violation(pp, np.arange(pp.S), before["D"], before["C"], D, C, E, theta, gamma) < 1e-6
+    # consensus: the reduced injection equals the sum of what the agents report; lambda step
+    inj = -pp.demand + (after["P"].sum(axis=0) + (D - C).sum(axis=0))[None, :]
+    # (rounding of a sum scales with the magnitude of the summands, not of the small residual)
+    mag = after["P"].sum(axis=0).max() + pp.demand.max()
+    assert np.abs(after["inj"] - inj).max() <= 1e-11 * mag + 1e-9
+    assert np.abs(after["lam"] - (lam_used + gamma * after["inj"].sum(axis=0))).max() < 1e-9 * max(1.0, np.abs(after["lam"]).max())
+    cost = float(pp.gen_mc @ after["P"].sum(axis=1) + pp.sto_mc @ (D + C).sum(axis=1))
+    assert abs(after["cost"][0] - cost) <= 1e-10 * cost
+    assert e.solver_failures() == 0
+
+
+def test_hip_config1_reaches_central_optimum(hip_api):
+    """BASELINE config 1 (1000 gens + 100 storages x 24): converges (gamma = 1/A) to the LP optimum."""
+    pp = synth.baseline_config(1)
+    A = pp.G + pp.S
+    e = make_engine(hip_api, pp, gamma=1.0 / A, max_iters=5000)
+    done, conv = e.iterate(5000)
+    assert conv and done < 2000
+    opt = solve_central(pp)["objective"]
+    assert abs(e.get_consensus()[4] - opt) / opt < 1e-3
