@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — ADMM consensus-OPF iterations on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2] [--gamma G]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one ADMM iteration (all agent x-updates + consensus + dual update + stop test) over one
+synthetic N-agent x T-timestep grid that is resident in HBM before the timed region starts.
+Prints ONE JSON line on rank 0:
+  metric/value   agent-subproblem-updates per second, whole job (= agents x iterations / s)
+  roofline       generator x-update kernel: algorithmic bytes per launch / its HIP-event duration
+  cpu_baseline   the oracle's exact mode (a "port", oracle/dopf_oracle.c) on the host cores, bounded sample
+Workloads (BASELINE.json `configs`): config1 = 1k gens + 100 storages x 24; config2 = 50k agents x 96
+(default: the largest single-GPU configuration); config4 = 1M agents x 24; config3 = 118-node/186-line
+synthetic network, 100k agents x 168. With --gpus N every rank holds one such grid (weak scaling) and
+the per-iteration consensus sum is one RCCL all-reduce.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "config1": (1, "synthetic 1k generators + 100 storages, 24 timesteps (BASELINE configs[1])"),
+    "config2": (2, "synthetic 50k agents (45455 gen + 4545 storage), 96 timesteps, copper plate (BASELINE configs[2])"),
+    "config3": (3, "synthetic 118-node/186-line network, 100k agents, 168 timesteps (BASELINE configs[3], graph is synthetic)"),
+    "config4": (4, "synthetic 1M agents (909091 gen + 90909 storage), 24 timesteps, copper plate (BASELINE configs[4])"),
+}
+
+
+def algorithmic_bytes(G, S, T, N, L):
+    """per generator update 16T+20 B, per storage update 40T+28 B, shared
+    consensus data (N+5L+2)*8T B once per GPU per iteration."""
+    gen = G * (16 * T + 20)
+    sto = S * (40 * T + 28)
+    shared = (N + 5 * L + 2) * 8 * T
+    return gen, sto, shared
+
+
+def cpu_baseline(pp, gamma, budget_s=20.0):
+    """Oracle (exact mode) on the host cores: a bounded number of iterations of the SAME problem."""
+    import numpy as np  # noqa: F401
+    from decentralopf_jl_amd import _capi
+    import __graft_entry__ as ge
+    if not os.path.exists(ge.ORACLE_LIB):
+        ge.build()
+    api = _capi.CApi(ge.ORACLE_LIB, "oracle_")
+    cores = os.cpu_count() or 1
+    e = _capi.Engine(api, params=_capi.default_params(gamma=gamma, eps=0.0), mode=1, **pp.engine_kwargs())
+    e.set_threads(cores)
+    t0 = time.perf_counter()
+    e.iterate(1)
+    t1 = time.perf_counter() - t0
+    n = 1
+    extra = int(max(0, min(50, (budget_s - t1) // max(t1, 1e-6))))
+    if extra > 0:
+        t0 = time.perf_counter()
+        e.iterate(extra)
+        t1 += time.perf_counter() - t0
+        n += extra
+    A = pp.G + pp.S
+    return {"value": A * n / t1, "unit": "agent-updates/s", "cores": cores, "kind": "port",
+            "sample": f"{n} ADMM iteration(s) of the same workload from the zero state, oracle exact mode, "
+                      f"OpenMP over agents ({t1:.1f} s)",
+            "iters_per_sec": n / t1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=48)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; marks the line invalid)")
+    ap.add_argument("--gamma", type=float, default=None, help="ADMM penalty (BASELINE's rho); default 1/A (convergent)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-iters", type=int, default=32)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import dopf_pkg
+    pkg = dopf_pkg.load()
+    from decentralopf_jl_amd import _capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    idx, desc = WORKLOADS[args.workload]
+    # weak scaling: every rank owns one full grid of the workload (own seed), demand adds up
+    base = synth.baseline_config(idx, scale=args.scale)
+    if world > 1:
+        cfg = dict(base.meta)
+        pp = synth.synthetic_case(cfg["n_gen"], cfg["n_sto"], cfg["T"], N=cfg["N"], L=cfg["L"], seed=synth.SEED + rank)
+        if cfg["L"] > 0:          # one network for everybody: rank 0's
+            pp.ptdf, pp.f_max = base.ptdf, base.f_max * world
+        dem = torch.tensor(pp.demand, dtype=torch.float64, device="cuda")
+        dist.all_reduce(dem)
+        pp.demand = dem.cpu().numpy()
+    else:
+        pp = base
+    A_local = pp.G + pp.S
+    A_global = A_local * world
+    gamma = args.gamma if args.gamma is not None else 1.0 / A_global
+
+    if world == 1:
+        eng = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, eps=0.0, device=local_rank),
+                           **pp.engine_kwargs())
+        step = lambda n: eng.iterate(n)
+        sync = lambda: eng.sync()
+    else:
+        from decentralopf_jl_amd.sharded import ShardedADMM
+        # ShardedADMM shards a global problem; here each rank already holds its own slice
+        sh = ShardedADMM.__new__(ShardedADMM)
+        sh.rank, sh.world, sh.problem, sh.shard = rank, world, pp, pp
+        kw = dict(gamma=gamma, eps=0.0, n_agents_global=A_global, device=local_rank,
+                  stream=torch.cuda.current_stream(local_rank).cuda_stream)
+        sh.engine = _capi.Engine(_capi.hip_api(), params=_capi.default_params(**kw), **pp.engine_kwargs())
+        sh._tensor = torch.zeros(sh.engine.consensus_size(), dtype=torch.float64, device="cuda")
+        sh.engine.bind_consensus(sh._tensor.data_ptr())
+        sh._all_reduce = lambda: dist.all_reduce(sh._tensor, op=dist.ReduceOp.SUM)
+        eng = sh.engine
+        step = lambda n: sh.step(n)
+        sync = lambda: sh.sync()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step(args.warmup)
+    sync()
+    barrier()
+    t0 = time.perf_counter()
+    step(args.steps)
+    sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    it_after, _ = sync()
+    assert it_after == 1 + args.warmup + args.steps, (it_after, args.warmup, args.steps)
+    fails = eng.solver_failures()
+
+    # per-kernel durations, live, HIP events on the streams the kernels run on (eager launches)
+    timing = eng.iterate_timed(args.timed_iters) if world == 1 else None
+
+    if rank == 0:
+        gen_b, sto_b, shared_b = algorithmic_bytes(pp.G, pp.S, pp.T, pp.N, pp.L)
+        out = {
+            "metric": "agent_subproblem_updates_per_sec", "value": A_global * args.steps / dt,
+            "unit": "agent-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "description": desc, "agents_per_gpu": A_local,
+                       "generators_per_gpu": pp.G, "storages_per_gpu": pp.S, "timesteps": pp.T,
+                       "nodes": pp.N, "lines": pp.L, "gamma": gamma, "w_flow": 10.0, "w_prox": 1.0,
+                       "parallelism": f"agents sharded x{world}, 1 all-reduce of {(pp.N + 2 * pp.L) * pp.T + 1} f64 per iteration"
+                       if world > 1 else "single GPU"},
+            "iters_per_sec": args.steps / dt,
+            "updates_per_sec_per_gpu": A_local * args.steps / dt,
+            "solver_failures": int(fails),
+        }
+        if args.scale != 1.0:
+            out["invalid"] = "scaled-down workload (debug run)"
+        if timing is not None:
+            peak = 8000.0        # GB/s, HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
+            ach = (gen_b + shared_b) / (timing["gen_ms"] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "k_gen_update", "achieved": ach, "peak": peak,
+                               "unit": "GB/s", "frac": ach / peak, "traffic": None,
+                               "algorithmic_bytes_per_launch": gen_b + shared_b,
+                               "kernel_ms": timing["gen_ms"]}
+            out["kernels_ms"] = {k: v for k, v in timing.items() if k != "iters"}
+            out["storage_kernel"] = {"algorithmic_bytes_per_launch": sto_b, "kernel_ms": timing["sto_ms"],
+                                     "achieved_GBps": sto_b / max(timing["sto_ms"], 1e-9) * 1e-6}
+            whole = (gen_b + sto_b + shared_b) / (dt / args.steps) / 1e9
+            out["whole_iteration_GBps"] = whole
+            out["whole_iteration_frac_of_peak"] = whole / peak
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pp, gamma)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

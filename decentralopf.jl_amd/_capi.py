@@ -42,6 +42,12 @@ class DopfParams(C.Structure):
     ]
 
 
+class DopfTiming(C.Structure):
+    _fields_ = [("tables_ms", C.c_double), ("gen_ms", C.c_double), ("sto_ms", C.c_double),
+                ("slack_ms", C.c_double), ("reduce_ms", C.c_double), ("dual_ms", C.c_double),
+                ("iter_ms", C.c_double), ("iters", C.c_int32)]
+
+
 F_NO_GRAPH = 1
 F_SERIAL_AGENTS = 2
 
@@ -106,6 +112,7 @@ class CApi:
         if prefix == "dopf_":
             self._sig("bind_consensus", C.c_int, [ctxp, C.c_void_p])
             self._sig("solver_failures", C.c_int64, [ctxp])
+            self._sig("iterate_timed", C.c_int, [ctxp, C.c_int32, C.POINTER(DopfTiming)])
             self._sig("version", C.c_char_p, [])
             self._sig("default_params", None, [C.POINTER(DopfParams)])
         else:   # oracle-only entry points (tests)
@@ -220,6 +227,12 @@ class Engine:
 
     def solver_failures(self) -> int:
         return int(self.api.solver_failures(self._ctx))
+
+    def iterate_timed(self, n_iters: int) -> dict:
+        """HIP-event timing of every kernel of the chain (eager launches), averages in ms."""
+        t = DopfTiming()
+        self._chk(self.api.iterate_timed(self._ctx, int(n_iters), C.byref(t)))
+        return {k: getattr(t, k) for k, _ in DopfTiming._fields_}
 
     def set_threads(self, n: int):
         self.api.set_threads(self._ctx, int(n))

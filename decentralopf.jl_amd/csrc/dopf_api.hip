@@ -254,6 +254,12 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     }
     v.nGenItems = (int)gitems.size();
     v.nStoItems = (int)sitems.size();
+    {
+        // level-1 reduce blocks per node: ~16 items per block, at most 64 (and N*RB blocks in total)
+        int max_items = 1;
+        for (int n = 0; n < N; ++n) max_items = std::max(max_items, (ngib[n + 1] - ngib[n]) + (nsib[n + 1] - nsib[n]));
+        v.reduceRB = std::max(1, std::min(64, (max_items + 15) / 16));
+    }
 
     const size_t NT = (size_t)N * T, LT = (size_t)L * T;
     TRY(dev_upload(c, &v.demand, std::vector<double>(p->demand, p->demand + NT)));
@@ -279,6 +285,8 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     }
     TRY(dev_alloc(c, &v.part_ginj, (size_t)v.nGenItems * T)); TRY(dev_alloc(c, &v.part_gcost, v.nGenItems));
     TRY(dev_alloc(c, &v.part_sinj, (size_t)v.nStoItems * T)); TRY(dev_alloc(c, &v.part_scost, v.nStoItems));
+    TRY(dev_alloc(c, &v.part2, (size_t)N * v.reduceRB * T)); TRY(dev_alloc(c, &v.part2_cost, v.reduceRB));
+    TRY(dev_alloc(c, &v.reduce_ticket, N));
     double *cons = nullptr;
     TRY(dev_alloc(c, &cons, NT + 2 * LT + 1));
     c->own_cons = cons;
@@ -337,6 +345,61 @@ int dopf_iterate(dopf_ctx *c, int32_t n_iters, int32_t *iters_done, int32_t *con
     if (rc) return rc;
     if (iters_done) *iters_done = c->host_st.iters_total - before;
     if (converged) *converged = c->host_st.converged;
+    return DOPF_OK;
+}
+
+int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
+{
+    if (!c || !out || n_iters < 1 || n_iters > 4096) return fail(c, DOPF_E_INVALID, "bad argument");
+    DeviceGuard guard(c->device);
+    const DevView &v = c->v;
+    enum { E_T0, E_T1, E_G0, E_G1, E_S0, E_S1, E_K0, E_K1, E_R1, E_D1, E_N };
+    std::vector<hipEvent_t> ev((size_t)n_iters * E_N);
+    for (auto &e : ev) HIPCHK(c, hipEventCreate(&e));
+    const bool fork = v.nGenItems > 0 && v.nStoItems > 0 && !(c->q.flags & DOPF_F_SERIAL_AGENTS);
+    for (int i = 0; i < n_iters; ++i) {
+        hipEvent_t *e = &ev[(size_t)i * E_N];
+        hipEventRecord(e[E_T0], c->main);
+        launch_tables(v, c->main);
+        hipEventRecord(e[E_T1], c->main);
+        hipStream_t ss = fork ? c->side : c->main;
+        if (fork) { hipEventRecord(c->evFork, c->main); hipStreamWaitEvent(c->side, c->evFork, 0); }
+        hipEventRecord(e[E_G0], c->main);
+        launch_gen_update(v, c->main);
+        hipEventRecord(e[E_G1], c->main);
+        hipEventRecord(e[E_S0], ss);
+        launch_sto_update(v, c->lc, ss);
+        hipEventRecord(e[E_S1], ss);
+        if (fork) { hipEventRecord(c->evJoin, c->side); hipStreamWaitEvent(c->main, c->evJoin, 0); }
+        hipEventRecord(e[E_K0], c->main);
+        launch_slack(v, c->main);
+        hipEventRecord(e[E_K1], c->main);
+        launch_reduce(v, c->main);
+        hipEventRecord(e[E_R1], c->main);
+        launch_dual(v, c->main);
+        hipEventRecord(e[E_D1], c->main);
+    }
+    HIPCHK(c, hipGetLastError());
+    int rc = read_status(c);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->side));
+    memset(out, 0, sizeof *out);
+    auto ms = [&](hipEvent_t a, hipEvent_t b) { float f = 0.f; hipEventElapsedTime(&f, a, b); return (double)f; };
+    for (int i = 0; i < n_iters; ++i) {
+        hipEvent_t *e = &ev[(size_t)i * E_N];
+        out->tables_ms += ms(e[E_T0], e[E_T1]);
+        out->gen_ms += ms(e[E_G0], e[E_G1]);
+        out->sto_ms += ms(e[E_S0], e[E_S1]);
+        out->slack_ms += ms(e[E_K0], e[E_K1]);
+        out->reduce_ms += ms(e[E_K1], e[E_R1]);
+        out->dual_ms += ms(e[E_R1], e[E_D1]);
+        out->iter_ms += ms(e[E_T0], e[E_D1]);
+    }
+    const double inv = 1.0 / n_iters;
+    out->tables_ms *= inv; out->gen_ms *= inv; out->sto_ms *= inv; out->slack_ms *= inv;
+    out->reduce_ms *= inv; out->dual_ms *= inv; out->iter_ms *= inv;
+    out->iters = n_iters;
+    for (auto &e : ev) hipEventDestroy(e);
     return DOPF_OK;
 }
 
@@ -551,6 +614,17 @@ int dopf_debug_table(dopf_ctx *c, int32_t n, int32_t t, double *beta, double *ps
     HIPCHK(c, hipMemcpy(slope, v.tb_slope + at * (v.M2 + 1), sizeof(double) * (v.M2 + 1), hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(psi0, v.tb_psi0 + at, sizeof(double), hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(m, v.tb_m + at, sizeof(int), hipMemcpyDeviceToHost));
+    return DOPF_OK;
+}
+
+// diagnostics (DOPF_STATS builds): cumulative storage-kernel counters {scans, wave loop trips, events}
+int dopf_debug_stats(dopf_ctx *c, uint64_t *out3)
+{
+    if (!c || !out3) return DOPF_E_INVALID;
+    DeviceGuard guard(c->device);
+    int rc = read_status(c);
+    if (rc) return rc;
+    out3[0] = c->host_st.dbg_scans; out3[1] = c->host_st.dbg_wave_loops; out3[2] = c->host_st.dbg_events;
     return DOPF_OK;
 }
 

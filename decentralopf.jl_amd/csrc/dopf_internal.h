@@ -33,6 +33,7 @@ struct Status {
     int halt;               // converged || iteration > max_iters: every kernel returns at once
     int iters_total;        // iterations computed since creation
     unsigned long long solver_fail;
+    unsigned long long dbg_scans, dbg_wave_loops, dbg_events;   // storage kernel statistics (DOPF_STATS builds)
     unsigned long long resbits[3];   // running max of |dual change| as bit patterns (>= 0 doubles)
     double res[3];          // lambda / mu / rho residual inf-norms of the last checked iteration
     double total_cost;
@@ -42,6 +43,7 @@ struct DevView {
     int N, L, T, G, S, M2;          // M2 = 2L
     int nGenItems, nStoItems;
     int genTT, genR;                // generator block tiling: TT = min(T, 512) timesteps x R agents
+    int reduceRB;                   // reduce blocks per node (two-level fixed-order sum)
     int max_iters;
     double gamma, w_flow, w_prox, eps, mask_thr, invA;
     // problem (read-only)
@@ -63,6 +65,8 @@ struct DevView {
     double *part_ginj, *part_gcost;                 // [item*T + t], [item]
     double *part_sinj, *part_scost;
     double *part_U, *part_K;                        // [(n*T + t)*L + l]
+    double *part2, *part2_cost;                     // [(n*RB + rb)*T + t], [rb]
+    int *reduce_ticket;                             // [n]
     double *cons;
     Status *st;
 };

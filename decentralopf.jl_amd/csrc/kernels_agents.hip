@@ -171,6 +171,9 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
         th0[c] = (!LINES && val[c]) ? v.price[it.node + N * t] + gam * v.s[t] : 0.0;
     }
     unsigned long long fails = 0;
+#ifdef DOPF_STATS
+    unsigned long long st_scans = 0, st_loops = 0, st_events = 0;
+#endif
     const int nRep = (it.a1 - it.a0 + NG - 1) / NG;
 
     for (int rep = 0; rep < nRep; ++rep) {
@@ -201,6 +204,10 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
 
         while (__any(k >= 0)) {
             const bool active = k >= 0;
+#ifdef DOPF_STATS
+            if (li == 0 && active) ++st_scans;
+            if (lane == 0) ++st_loops;
+#endif
             // -- forward scan of the clamp-add maps e -> clamp(e + x_t(nu), 0, em) at price nu
             double Dv[NCH], Cv[NCH], Sv[NCH], sg[NCH];
             double e_in = 0.0;
@@ -351,6 +358,9 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
                     else { nu = (res < 0.0) ? nu + step : nu - step; step *= 4.0; }
                     mode = 1;
                     rit = 0;
+#ifdef DOPF_STATS
+                    if (li == 0) { ++st_events; if (!(sl > 0.0)) st_loops += (1ull << 32); }
+#endif
                 }
             }
         }
@@ -401,6 +411,11 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
     }
     if (tid == 0) v.part_scost[blockIdx.x] = redc[0];
     if (fails) atomicAdd(&v.st->solver_fail, fails);
+#ifdef DOPF_STATS
+    if (st_scans) atomicAdd(&v.st->dbg_scans, st_scans);
+    if (st_loops) atomicAdd(&v.st->dbg_wave_loops, st_loops);
+    if (st_events) atomicAdd(&v.st->dbg_events, st_events);
+#endif
 }
 
 bool sto_config_supported(int T, Launch *lc)

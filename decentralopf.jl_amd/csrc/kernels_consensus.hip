@@ -202,26 +202,35 @@ void launch_slack(const DevView &v, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------
-// reduce: blocks [0,N) sum the item partials of one node; the rest sum part_U / part_K over nodes
+// reduce: RB blocks per node sum slices of the node's item partials (level 1); the block that
+// finishes last for a node adds the RB slice sums in slice order (level 2) — the order of every
+// addition is fixed, so the result is bitwise reproducible whichever block happens to be last.
+// Remaining blocks sum part_U / part_K over nodes.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_reduce(DevView v)
 {
     if (v.st->halt) return;
     __shared__ double red[256];
+    __shared__ int last_sh;
     const int tid = threadIdx.x;
-    const int N = v.N, L = v.L, T = v.T;
-    if ((int)blockIdx.x < N) {
-        const int n = blockIdx.x;
+    const int N = v.N, L = v.L, T = v.T, RB = v.reduceRB;
+    if ((int)blockIdx.x < N * RB) {
+        const int n = blockIdx.x / RB, rb = blockIdx.x - n * RB;
         const int TT = T < 256 ? T : 256, R = 256 / TT;
         const int r = tid / TT, tt = tid - r * TT;
-        const int g0 = v.node_gitem_beg[n], g1 = v.node_gitem_beg[n + 1];
-        const int s0 = v.node_sitem_beg[n], s1 = v.node_sitem_beg[n + 1];
+        const int g0 = v.node_gitem_beg[n], ngi = v.node_gitem_beg[n + 1] - g0;
+        const int s0 = v.node_sitem_beg[n], nsi = v.node_sitem_beg[n + 1] - s0;
+        const int ni = ngi + nsi;                       // generator items first, then storage items
+        const int per = (ni + RB - 1) / RB;
+        const int i0 = rb * per, i1 = min(ni, i0 + per);
+        double *p2 = v.part2 + ((size_t)n * RB + rb) * T;
         for (int tc = 0; tc < T; tc += TT) {
             const int t = tc + tt;
             double acc = 0.0;
             if (r < R && t < T) {
-                for (int i = g0 + r; i < g1; i += R) acc += v.part_ginj[(size_t)i * T + t];
-                for (int i = s0 + r; i < s1; i += R) acc += v.part_sinj[(size_t)i * T + t];
+#pragma unroll 4
+                for (int i = i0 + r; i < i1; i += R)
+                    acc += i < ngi ? v.part_ginj[(size_t)(g0 + i) * T + t] : v.part_sinj[(size_t)(s0 + i - ngi) * T + t];
             }
             __syncthreads();
             red[tid] = acc;
@@ -229,19 +238,44 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
             if (r == 0 && t < T) {
                 double sum = 0.0;
                 for (int q = 0; q < R; ++q) sum += red[q * TT + tt];
-                v.cons[n + (size_t)N * t] = sum;
+                p2[t] = sum;
             }
         }
+        // cost partials ride with the first node's slices
         if (n == 0) {
+            const int nc = v.nGenItems + v.nStoItems, cper = (nc + RB - 1) / RB;
+            const int c0 = rb * cper, c1 = min(nc, c0 + cper);
             double c = 0.0;
-            for (int i = tid; i < v.nGenItems; i += 256) c += v.part_gcost[i];
-            for (int i = tid; i < v.nStoItems; i += 256) c += v.part_scost[i];
+            for (int i = c0 + tid; i < c1; i += 256) c += i < v.nGenItems ? v.part_gcost[i] : v.part_scost[i - v.nGenItems];
             c = block_sum256(c, red);
-            if (tid == 0) v.cons[(size_t)N * T + 2 * (size_t)L * T] = c;
+            if (tid == 0) v.part2_cost[rb] = c;
+        }
+        // publish, take a ticket; the last block of this node finishes the sum
+        // (agent-scope release by every storing thread, drained before the ticket; the last block
+        //  acquires before it reads the other blocks' slices — cdna_hip_programming.md G16)
+        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) last_sh = (atomicAdd(&v.reduce_ticket[n], 1) == RB - 1);
+        __syncthreads();
+        if (last_sh) {
+            __threadfence();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int t = tid; t < T; t += 256) {
+                double sum = 0.0;
+                for (int q = 0; q < RB; ++q) sum += v.part2[((size_t)n * RB + q) * T + t];
+                v.cons[n + (size_t)N * t] = sum;
+            }
+            if (n == 0 && tid == 0) {
+                double c = 0.0;
+                for (int q = 0; q < RB; ++q) c += v.part2_cost[q];
+                v.cons[(size_t)N * T + 2 * (size_t)L * T] = c;
+            }
+            if (tid == 0) v.reduce_ticket[n] = 0;       // ready for the next iteration
         }
     } else {
         const size_t LT = (size_t)L * T;
-        const size_t idx = (size_t)(blockIdx.x - N) * 256 + tid;
+        const size_t idx = (size_t)(blockIdx.x - N * RB) * 256 + tid;
         if (idx < 2 * LT) {
             const int which = idx >= LT;
             const size_t rem = idx - which * LT;            // l + L*t
@@ -257,7 +291,7 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
 void launch_reduce(const DevView &v, hipStream_t s)
 {
     const size_t LT2 = 2 * (size_t)v.L * v.T;
-    const int blocks = v.N + (int)((LT2 + 255) / 256);
+    const int blocks = v.N * v.reduceRB + (int)((LT2 + 255) / 256);
     hipLaunchKernelGGL(k_reduce, dim3(blocks), dim3(256), 0, s, v);
 }
 

@@ -147,6 +147,15 @@ int dopf_set_state(dopf_ctx *ctx, const double *P, const double *D, const double
 
 /* Diagnostics: number of storage sub-problems whose inner root search hit its iteration cap
  * since creation (0 in every healthy run), and a version string. */
+/* Measurement: n_iters iterations launched kernel by kernel (no graph) with a hipEvent pair around
+ * every kernel on the stream it runs on; one host sync at the end. Average milliseconds per launch. */
+typedef struct dopf_timing {
+    double tables_ms, gen_ms, sto_ms, slack_ms, reduce_ms, dual_ms;  /* per-kernel averages     */
+    double iter_ms;                                                  /* whole iteration, event to event */
+    int32_t iters;
+} dopf_timing;
+int dopf_iterate_timed(dopf_ctx *ctx, int32_t n_iters, dopf_timing *out);
+
 int64_t dopf_solver_failures(dopf_ctx *ctx);
 /* Diagnostics (L > 0): the breakpoint table of node n, timestep t that the last x-update used:
  * beta, psi: 2L doubles (first *m valid, ascending), slope: 2L+1, psi0 = Psi(0). */
