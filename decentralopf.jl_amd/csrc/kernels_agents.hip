@@ -117,20 +117,91 @@ void launch_gen_update(const DevView &v, hipStream_t s)
 // ------------------------------------------------------------------------------------------------
 // storages
 // ------------------------------------------------------------------------------------------------
+//
+// A group of LPS lanes owns one storage; lane li owns the NCH CONSECUTIVE timesteps li*NCH .. li*NCH+NCH-1.
+// One "scan" evaluates, for a trial price nu, the whole forward recursion
+//     F_t = clamp(F_{t-1} + x_t(nu), 0, emax),  F_0 = 0
+// as an associative scan of clamp-add maps e -> clamp(e + A, LO, HI): NCH maps are composed inside the
+// lane, the lane composites are scanned across the group with DPP row shifts / row broadcasts (no LDS
+// traffic), and the prefix is applied back inside the lane.
 
-// argmin over [0,pm]^2 of the strictly convex quadratic with gradient (a D - b C - rD, a C - b D - rC),
-// a > b >= 0; sg = d(C - D)/d(nu) on the active piece (rD falls, rC rises with nu at unit rate).
-__device__ __forceinline__ void box2(double a, double b, double rD, double rC, double pm, double &D,
-                                     double &C, double &sg)
+struct Map3 {
+    double A, LO, HI;
+};
+
+__device__ __forceinline__ Map3 compose(const Map3 &p, const Map3 &c)   // p first, then c
 {
-    const double ia = 1.0 / a;
-    const double Df = clampd((a * rD + b * rC) / (a * a - b * b), 0.0, pm);
-    const double Cf = (rC + b * Df) * ia;
-    if (Cf < 0.0) { C = 0.0; D = clampd(rD * ia, 0.0, pm); }
-    else if (Cf > pm) { C = pm; D = clampd((rD + b * pm) * ia, 0.0, pm); }
-    else { C = Cf; D = Df; }
-    const bool fD = D > 0.0 && D < pm, fC = C > 0.0 && C < pm;
-    sg = (fD && fC) ? 2.0 / (a + b) : ((fD || fC) ? ia : 0.0);
+    Map3 r;
+    r.A = p.A + c.A;
+    r.LO = clampd(p.LO + c.A, c.LO, c.HI);
+    r.HI = clampd(p.HI + c.A, c.LO, c.HI);
+    return r;
+}
+
+// lanes whose DPP source is out of range (or whose row is masked off) keep `oldv`
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dppd(double oldv, double src)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(oldv), __double2loint(src), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(oldv), __double2hiint(src), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Map3 dppm(const Map3 &m)
+{
+    Map3 p;
+    p.A = dppd<CTRL, ROW_MASK>(m.A, m.A);
+    p.LO = dppd<CTRL, ROW_MASK>(m.LO, m.LO);
+    p.HI = dppd<CTRL, ROW_MASK>(m.HI, m.HI);
+    return p;
+}
+
+// inclusive scan of the lane composites over the lanes of each group
+template <int LPS>
+__device__ __forceinline__ void scan_maps(Map3 &m, int lane)
+{
+    const int r = lane & ((LPS < 16 ? LPS : 16) - 1);
+    { const Map3 p = dppm<0x111, 0xF>(m); if (r >= 1) m = compose(p, m); }                     // row_shr:1
+    if (LPS >= 4) { const Map3 p = dppm<0x112, 0xF>(m); if (r >= 2) m = compose(p, m); }       // row_shr:2
+    if (LPS >= 8) { const Map3 p = dppm<0x114, 0xF>(m); if (r >= 4) m = compose(p, m); }       // row_shr:4
+    if (LPS >= 16) { const Map3 p = dppm<0x118, 0xF>(m); if (r >= 8) m = compose(p, m); }      // row_shr:8
+    if (LPS >= 32) { const Map3 p = dppm<0x142, 0xA>(m); if (lane & 16) m = compose(p, m); }   // row_bcast:15
+    if (LPS >= 64) { const Map3 p = dppm<0x143, 0xC>(m); if (lane & 32) m = compose(p, m); }   // row_bcast:31
+}
+
+// value of the previous lane of the group (garbage for the group's first lane: caller masks it)
+template <int LPS>
+__device__ __forceinline__ double prev_lane(double x)
+{
+    if (LPS <= 16) return dppd<0x111, 0xF>(x, x);      // row_shr:1
+    return dppd<0x138, 0xF>(x, x);                     // wave_shr:1
+}
+
+template <int LPS>
+__device__ __forceinline__ double group_sum(double x)
+{
+    if (LPS >= 2) x += dppd<0xB1, 0xF>(x, x);          // quad_perm [1,0,3,2]
+    if (LPS >= 4) x += dppd<0x4E, 0xF>(x, x);          // quad_perm [2,3,0,1]
+    if (LPS >= 8) x += dppd<0x141, 0xF>(x, x);         // row_half_mirror
+    if (LPS >= 16) x += dppd<0x140, 0xF>(x, x);        // row_mirror
+    if (LPS >= 32) x += __shfl_xor(x, 16);
+    if (LPS >= 64) x += __shfl_xor(x, 32);
+    return x;
+}
+
+// inclusive prefix sum over the lanes of each group
+template <int LPS>
+__device__ __forceinline__ double scan_sum(double x, int lane)
+{
+    const int r = lane & ((LPS < 16 ? LPS : 16) - 1);
+    { const double p = dppd<0x111, 0xF>(0.0, x); if (r >= 1) x += p; }
+    if (LPS >= 4) { const double p = dppd<0x112, 0xF>(0.0, x); if (r >= 2) x += p; }
+    if (LPS >= 8) { const double p = dppd<0x114, 0xF>(0.0, x); if (r >= 4) x += p; }
+    if (LPS >= 16) { const double p = dppd<0x118, 0xF>(0.0, x); if (r >= 8) x += p; }
+    if (LPS >= 32) { const double p = dppd<0x142, 0xA>(0.0, x); if (lane & 16) x += p; }
+    if (LPS >= 64) { const double p = dppd<0x143, 0xC>(0.0, x); if (lane & 32) x += p; }
+    return x;
 }
 
 template <int LPS>
@@ -141,34 +212,49 @@ __device__ __forceinline__ unsigned long long group_bits(bool pred, int gbase)
     return (b >> gbase) & ((1ull << LPS) - 1ull);
 }
 
+// argmin over [0,pm]^2 of the strictly convex quadratic with gradient (a D - b C - rD, a C - b D - rC),
+// a > b >= 0, given ia = 1/a, idet = 1/(a^2 - b^2); sg = d(C - D)/d(nu) on the active piece
+// (rD falls, rC rises with nu at unit rate): 2/(a+b) with both free, 1/a with one, 0 with none.
+// With C "free" D solves a 1-D convex problem (clamp of its stationary point); if the implied C leaves
+// the box, C sits on that bound (monotone contraction argument).
+__device__ __forceinline__ void box2(double a, double b, double ia, double idet, double s2, double rD,
+                                     double rC, double pm, double &D, double &C, double &sg)
+{
+    const double Df = clampd((a * rD + b * rC) * idet, 0.0, pm);
+    const double Cf = (rC + b * Df) * ia;
+    const double Dlo = clampd(rD * ia, 0.0, pm), Dhi = clampd((rD + b * pm) * ia, 0.0, pm);
+    C = clampd(Cf, 0.0, pm);
+    D = Cf < 0.0 ? Dlo : (Cf > pm ? Dhi : Df);
+    const bool fD = D > 0.0 && D < pm, fC = C > 0.0 && C < pm;
+    sg = (fD && fC) ? s2 : ((fD || fC) ? ia : 0.0);
+}
+
 struct StoAgent {
     double mc, pm, em;
 };
 
-// Block = one Item of storages at one node; a group of LPS lanes owns one storage at a time,
-// lane li of chunk c owns timestep c*LPS + li.
 template <int LPS, int NCH, bool LINES>
 __global__ __launch_bounds__(256) void k_sto_update(DevView v)
 {
     if (v.st->halt) return;
     constexpr int NG = 256 / LPS;
-    __shared__ double red[NG * NCH * LPS];
+    __shared__ double red[NG * LPS * NCH];
     __shared__ double redc[256];
     const int tid = threadIdx.x, lane = tid & 63, li = tid & (LPS - 1), grp = tid / LPS;
     const int gbase = lane & ~(LPS - 1);
     const Item it = v.sto_items[blockIdx.x];
     const int T = v.T, N = v.N;
     const double w = v.w_prox, gam = v.gamma;
+    const double a0 = w + gam, ia0 = 1.0 / a0, idet0 = 1.0 / (a0 * a0 - gam * gam), s20 = 2.0 / (a0 + gam);
+    const int tbase = li * NCH;
 
-    bool val[NCH];
     double th0[NCH], accQ[NCH];
     double accCost = 0.0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int t = c * LPS + li;
-        val[c] = t < T;
+        const int t = tbase + c;
         accQ[c] = 0.0;
-        th0[c] = (!LINES && val[c]) ? v.price[it.node + N * t] + gam * v.s[t] : 0.0;
+        th0[c] = (!LINES && t < T) ? v.price[it.node + N * t] + gam * v.s[t] : 0.0;
     }
     unsigned long long fails = 0;
 #ifdef DOPF_STATS
@@ -183,17 +269,51 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
         ag.mc = live ? v.sto_mc[s] : 0.0;
         ag.pm = live ? v.sto_pmax[s] : 0.0;
         ag.em = live ? v.sto_emax[s] : 0.0;
-        double D0[NCH], C0[NCH], Dn[NCH], Cn[NCH];
+        // rD0/rC0: the nu-independent part of the two gradient offsets (copper plate); D0/C0 otherwise
+        double D0[NCH], C0[NCH], nuf[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const bool ok = live && val[c];
-            const size_t e = (size_t)s * T + (c * LPS + li);
+            const int t = tbase + c;
+            const bool ok = live && t < T;
+            const size_t e = (size_t)s * T + t;
             D0[c] = ok ? v.D[e] : 0.0;
             C0[c] = ok ? v.C[e] : 0.0;
-            Dn[c] = 0.0;
-            Cn[c] = 0.0;
+            nuf[c] = 0.0;
         }
         const double tol = 1e-11 * (1.0 + ag.em);
+
+        // x_t(nu): net charge of timestep (li, c) at price nu
+        auto eval = [&](int c, double nu, double &dd, double &cc, double &s1) {
+            const int t = tbase + c;
+            const double q0 = D0[c] - C0[c];
+            if (!LINES) {
+                const double theta = th0[c] - gam * q0;
+                box2(a0, gam, ia0, idet0, s20, w * D0[c] - ag.mc - theta - nu, w * C0[c] - ag.mc + theta + nu,
+                     ag.pm, dd, cc, s1);
+            } else {
+                const size_t at = (size_t)it.node + (size_t)N * t;
+                const int m = v.tb_m[at];
+                const double *beta = v.tb_beta + at * v.M2, *psi = v.tb_psi + at * v.M2;
+                const double *slope = v.tb_slope + at * (v.M2 + 1);
+                double ab = 0.0, ap = v.tb_psi0[at], kap = slope[0];
+                if (m > 0) {
+                    int l2 = 0, h2 = m;       // first kink where dlt - (D(z) - C(z) - q0) >= 0
+                    while (l2 < h2) {
+                        const int mid = (l2 + h2) >> 1;
+                        const double z = psi[mid] + nu;
+                        const double Dz = clampd(D0[c] - (ag.mc + z) / w, 0.0, ag.pm);
+                        const double Cz = clampd(C0[c] - (ag.mc - z) / w, 0.0, ag.pm);
+                        if (beta[mid] - (Dz - Cz - q0) >= 0.0) h2 = mid; else l2 = mid + 1;
+                    }
+                    const int a = l2 < m ? l2 : m - 1;
+                    ab = beta[a]; ap = psi[a]; kap = slope[l2];
+                }
+                const double theta = ap - kap * (ab + q0);
+                const double a = w + kap;
+                box2(a, kap, 1.0 / a, 1.0 / (a * a - kap * kap), 2.0 / (a + kap), w * D0[c] - ag.mc - theta - nu,
+                     w * C0[c] - ag.mc + theta + nu, ag.pm, dd, cc, s1);
+            }
+        };
 
         // ---- price-threshold recursion, backwards over constant-price segments -------------------
         double nu = 0.0;
@@ -208,83 +328,58 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
             if (li == 0 && active) ++st_scans;
             if (lane == 0) ++st_loops;
 #endif
-            // -- forward scan of the clamp-add maps e -> clamp(e + x_t(nu), 0, em) at price nu
-            double Dv[NCH], Cv[NCH], Sv[NCH], sg[NCH];
-            double e_in = 0.0;
+            // -- one scan at price nu
+            double x[NCH], sg[NCH], Sv[NCH];
+            Map3 loc;
+            loc.A = 0.0; loc.LO = -INFINITY; loc.HI = INFINITY;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                const int t = c * LPS + li;
+                const int t = tbase + c;
                 double dd = 0.0, cc = 0.0, s1 = 0.0;
-                if (val[c] && t <= k) {
-                    const double q0 = D0[c] - C0[c];
-                    double theta, kap;
-                    if (!LINES) {
-                        theta = th0[c] - gam * q0;
-                        kap = gam;
-                    } else {
-                        const size_t at = (size_t)it.node + (size_t)N * t;
-                        const int m = v.tb_m[at];
-                        const double *beta = v.tb_beta + at * v.M2, *psi = v.tb_psi + at * v.M2;
-                        const double *slope = v.tb_slope + at * (v.M2 + 1);
-                        double ab = 0.0, ap = v.tb_psi0[at];
-                        kap = slope[0];
-                        if (m > 0) {
-                            int l2 = 0, h2 = m;   // first kink where dlt - (D(z) - C(z) - q0) >= 0
-                            while (l2 < h2) {
-                                const int mid = (l2 + h2) >> 1;
-                                const double z = psi[mid] + nu;
-                                const double Dz = clampd(D0[c] - (ag.mc + z) / w, 0.0, ag.pm);
-                                const double Cz = clampd(C0[c] - (ag.mc - z) / w, 0.0, ag.pm);
-                                if (beta[mid] - (Dz - Cz - q0) >= 0.0) h2 = mid; else l2 = mid + 1;
-                            }
-                            const int a = l2 < m ? l2 : m - 1;
-                            ab = beta[a]; ap = psi[a]; kap = slope[l2];
-                        }
-                        theta = ap - kap * (ab + q0);
-                    }
-                    box2(w + kap, kap, w * D0[c] - ag.mc - theta - nu, w * C0[c] - ag.mc + theta + nu,
-                         ag.pm, dd, cc, s1);
-                }
-                Dv[c] = dd; Cv[c] = cc; sg[c] = s1;
-                const double x = cc - dd;
-                double A = x, LO = 0.0, HI = ag.em;
+                if (t <= k && t < T) eval(c, nu, dd, cc, s1);
+                x[c] = cc - dd;
+                sg[c] = s1;
+                loc.A += x[c];
+                loc.LO = clampd(loc.LO + x[c], 0.0, ag.em);
+                loc.HI = clampd(loc.HI + x[c], 0.0, ag.em);
+            }
+            Map3 inc = loc;
+            scan_maps<LPS>(inc, lane);
+            Map3 ex;
+            ex.A = prev_lane<LPS>(inc.A); ex.LO = prev_lane<LPS>(inc.LO); ex.HI = prev_lane<LPS>(inc.HI);
+            double e = li == 0 ? 0.0 : clampd(ex.A, ex.LO, ex.HI);
 #pragma unroll
-                for (int d = 1; d < LPS; d <<= 1) {
-                    const double pA = __shfl_up(A, d, LPS), pLO = __shfl_up(LO, d, LPS), pHI = __shfl_up(HI, d, LPS);
-                    if (li >= d) {
-                        const double nLO = clampd(pLO + A, LO, HI), nHI = clampd(pHI + A, LO, HI);
-                        A += pA; LO = nLO; HI = nHI;
-                    }
-                }
-                const double F = clampd(e_in + A, LO, HI);
-                double Fp = __shfl_up(F, 1, LPS);
-                if (li == 0) Fp = e_in;
-                Sv[c] = Fp + x;
-                e_in = __shfl(F, LPS - 1, LPS);
+            for (int c = 0; c < NCH; ++c) {
+                Sv[c] = e + x[c];
+                e = clampd(Sv[c], 0.0, ag.em);
             }
 
-            bool classify = active && mode == 0;
-            if (active && mode == 1) {
-                // value of S_vv(nu) and its slope: sum of sg over the run of unclamped steps ending at vv
-                const int cv = vv / LPS, lv = vv & (LPS - 1);
+            // -- unclamped level at vv and its slope (only meaningful in mode 1 / when a new event starts)
+            auto level_and_slope = [&](int idx, double &sv, double &sl) {
+                const int lown = idx / NCH, cown = idx - lown * NCH;
                 double sel = 0.0;
                 int jlast = -1;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    if (c == cv) sel = Sv[c];
-                    const int t = c * LPS + li;
-                    const unsigned long long b = group_bits<LPS>(t < vv && (Sv[c] <= 0.0 || Sv[c] >= ag.em), gbase);
-                    if (b) jlast = c * LPS + (63 - __clzll(b));
+                    if (c == cown) sel = Sv[c];
+                    const int t = tbase + c;
+                    const unsigned long long b = group_bits<LPS>(t < idx && (Sv[c] <= 0.0 || Sv[c] >= ag.em), gbase);
+                    if (b) { const int j = (63 - __clzll(b)) * NCH + c; jlast = j > jlast ? j : jlast; }
                 }
-                const double sv = __shfl(sel, lv, LPS);
-                double sl = 0.0;
+                sv = __shfl(sel, gbase + lown);
+                double part = 0.0;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    const int t = c * LPS + li;
-                    if (t > jlast && t <= vv) sl += sg[c];
+                    const int t = tbase + c;
+                    if (t > jlast && t <= idx) part += sg[c];
                 }
-#pragma unroll
-                for (int d = LPS >> 1; d > 0; d >>= 1) sl += __shfl_xor(sl, d, LPS);
+                sl = group_sum<LPS>(part);
+            };
+
+            bool classify = active && mode == 0;
+            if (active && mode == 1) {
+                double sv, sl;
+                level_and_slope(vv, sv, sl);
                 const double res = sv - target;
                 if (res < 0.0) lo = nu; else hi = nu;
                 bool conv = fabs(res) <= 1e-12 * (1.0 + ag.em) || rit >= 80;
@@ -303,7 +398,7 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
                     if (rit >= 80 && fabs(res) > 1e-7 * (1.0 + ag.em) && li == 0) ++fails;
 #pragma unroll
                     for (int c = 0; c < NCH; ++c)
-                        if (c * LPS + li == vv) { Dn[c] = Dv[c]; Cn[c] = Cv[c]; }
+                        if (tbase + c == vv) nuf[c] = nu;
                     k = vv - 1;
                     mode = 0;
                     classify = k >= 0;
@@ -317,37 +412,20 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
                 int vnew = -1;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    const int t = c * LPS + li;
-                    const unsigned long long b = group_bits<LPS>(val[c] && t <= k && (Sv[c] < -tol || Sv[c] > ag.em + tol), gbase);
-                    if (b) vnew = c * LPS + (63 - __clzll(b));
+                    const int t = tbase + c;
+                    const unsigned long long b = group_bits<LPS>(t <= k && t < T && (Sv[c] < -tol || Sv[c] > ag.em + tol), gbase);
+                    if (b) { const int j = (63 - __clzll(b)) * NCH + c; vnew = j > vnew ? j : vnew; }
                 }
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    const int t = c * LPS + li;
-                    if (t > vnew && t <= k) { Dn[c] = Dv[c]; Cn[c] = Cv[c]; }
+                    const int t = tbase + c;
+                    if (t > vnew && t <= k) nuf[c] = nu;
                 }
                 if (vnew < 0) {
                     k = -1;
                 } else {
-                    const int cv = vnew / LPS, lv = vnew & (LPS - 1);
-                    double sel = 0.0;
-                    int jlast = -1;
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        if (c == cv) sel = Sv[c];
-                        const int t = c * LPS + li;
-                        const unsigned long long b = group_bits<LPS>(t < vnew && (Sv[c] <= 0.0 || Sv[c] >= ag.em), gbase);
-                        if (b) jlast = c * LPS + (63 - __clzll(b));
-                    }
-                    const double sv = __shfl(sel, lv, LPS);
-                    double sl = 0.0;
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        const int t = c * LPS + li;
-                        if (t > jlast && t <= vnew) sl += sg[c];
-                    }
-#pragma unroll
-                    for (int d = LPS >> 1; d > 0; d >>= 1) sl += __shfl_xor(sl, d, LPS);
+                    double sv, sl;
+                    level_and_slope(vnew, sv, sl);
                     vv = vnew;
                     target = sv < 0.0 ? 0.0 : ag.em;
                     const double res = sv - target;
@@ -359,26 +437,29 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
                     mode = 1;
                     rit = 0;
 #ifdef DOPF_STATS
-                    if (li == 0) { ++st_events; if (!(sl > 0.0)) st_loops += (1ull << 32); }
+                    if (li == 0) ++st_events;
 #endif
                 }
             }
         }
 
-        // ---- level E = cumsum(C - D), outputs, partial sums ----------------------------------------
-        double carry = 0.0;
+        // ---- final (D, C) at each timestep's price, level E = cumsum(C - D), outputs, partial sums ------
+        double Dn[NCH], Cn[NCH], run = 0.0;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            double x = Cn[c] - Dn[c];
+            double s1;
+            Dn[c] = 0.0; Cn[c] = 0.0;
+            if (live && tbase + c < T) eval(c, nuf[c], Dn[c], Cn[c], s1);
+            run += Cn[c] - Dn[c];
+        }
+        const double incl = scan_sum<LPS>(run, lane);
+        const double incl_prev = prev_lane<LPS>(incl);     // DPP: every lane must execute it (no ?: around it)
+        double ev = li == 0 ? 0.0 : incl_prev;
 #pragma unroll
-            for (int d = 1; d < LPS; d <<= 1) {
-                const double px = __shfl_up(x, d, LPS);
-                if (li >= d) x += px;
-            }
-            const double ev = carry + x;
-            carry = __shfl(ev, LPS - 1, LPS);
-            if (live && val[c]) {
-                const size_t e = (size_t)s * T + (c * LPS + li);
+        for (int c = 0; c < NCH; ++c) {
+            ev += Cn[c] - Dn[c];
+            if (live && tbase + c < T) {
+                const size_t e = (size_t)s * T + (tbase + c);
                 v.D[e] = Dn[c];
                 v.C[e] = Cn[c];
                 v.E[e] = ev;
@@ -391,16 +472,16 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
 
     // fixed-order block reduction of the per-timestep sums over the NG groups
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) red[(grp * NCH + c) * LPS + li] = accQ[c];
+    for (int c = 0; c < NCH; ++c) red[(grp * LPS + li) * NCH + c] = accQ[c];
     redc[tid] = accCost;
     __syncthreads();
     if (grp == 0) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int t = c * LPS + li;
+            const int t = tbase + c;
             if (t < T) {
                 double sum = 0.0;
-                for (int g2 = 0; g2 < NG; ++g2) sum += red[(g2 * NCH + c) * LPS + li];
+                for (int g2 = 0; g2 < NG; ++g2) sum += red[(g2 * LPS + li) * NCH + c];
                 v.part_sinj[(size_t)blockIdx.x * T + t] = sum;
             }
         }
@@ -420,13 +501,12 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
 
 bool sto_config_supported(int T, Launch *lc)
 {
-    // smallest lane group that covers T in <= 3 chunks; groups wider than 8 lanes are always
-    // instantiated with 3 chunks (a chunk past T is masked out) to keep the kernel count small
+    // lane group x consecutive timesteps per lane; LPS <= 16 keeps every cross-lane step a DPP row op
     if (T <= 24) { lc->stoLPS = 8; lc->stoNCH = (T + 7) / 8; return true; }
     if (T <= 48) { lc->stoLPS = 16; lc->stoNCH = 3; return true; }
-    if (T <= 96) { lc->stoLPS = 32; lc->stoNCH = 3; return true; }
-    if (T <= 192) { lc->stoLPS = 64; lc->stoNCH = 3; return true; }
-    if (T <= 256) { lc->stoLPS = 64; lc->stoNCH = 4; return true; }
+    if (T <= 96) { lc->stoLPS = 16; lc->stoNCH = 6; return true; }
+    if (T <= 192) { lc->stoLPS = 32; lc->stoNCH = 6; return true; }
+    if (T <= 384) { lc->stoLPS = 64; lc->stoNCH = 6; return true; }
     if (T <= 512) { lc->stoLPS = 64; lc->stoNCH = 8; return true; }
     return false;
 }
@@ -443,9 +523,9 @@ void launch_sto_update(const DevView &v, const Launch &lc, hipStream_t s)
     if (v.nStoItems == 0) return;
 #define DOPF_CASE(LPS_, NCH_) if (lc.stoLPS == LPS_ && lc.stoNCH == NCH_) { launch_sto_t<LPS_, NCH_>(v, s); return; }
     DOPF_CASE(8, 1) DOPF_CASE(8, 2) DOPF_CASE(8, 3)
-    DOPF_CASE(16, 3)
-    DOPF_CASE(32, 3)
-    DOPF_CASE(64, 3) DOPF_CASE(64, 4) DOPF_CASE(64, 8)
+    DOPF_CASE(16, 3) DOPF_CASE(16, 6)
+    DOPF_CASE(32, 3) DOPF_CASE(32, 6)
+    DOPF_CASE(64, 6) DOPF_CASE(64, 8)
 #undef DOPF_CASE
 }
 
