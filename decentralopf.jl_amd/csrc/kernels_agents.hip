@@ -190,6 +190,18 @@ __device__ __forceinline__ double group_sum(double x)
     return x;
 }
 
+template <int LPS>
+__device__ __forceinline__ double group_min(double x)
+{
+    if (LPS >= 2) x = fmin(x, dppd<0xB1, 0xF>(x, x));
+    if (LPS >= 4) x = fmin(x, dppd<0x4E, 0xF>(x, x));
+    if (LPS >= 8) x = fmin(x, dppd<0x141, 0xF>(x, x));
+    if (LPS >= 16) x = fmin(x, dppd<0x140, 0xF>(x, x));
+    if (LPS >= 32) x = fmin(x, __shfl_xor(x, 16));
+    if (LPS >= 64) x = fmin(x, __shfl_xor(x, 32));
+    return x;
+}
+
 // inclusive prefix sum over the lanes of each group
 template <int LPS>
 __device__ __forceinline__ double scan_sum(double x, int lane)
@@ -354,39 +366,79 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
                 e = clampd(Sv[c], 0.0, ag.em);
             }
 
-            // -- unclamped level at vv and its slope (only meaningful in mode 1 / when a new event starts)
-            auto level_and_slope = [&](int idx, double &sv, double &sl) {
+            // -- helpers on the scan just made: unclamped level at a timestep, its slope in nu, and
+            //    the way out of a flat piece
+            auto level_at = [&](int idx) -> double {
                 const int lown = idx / NCH, cown = idx - lown * NCH;
                 double sel = 0.0;
-                int jlast = -1;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+                    if (c == cown) sel = Sv[c];
+                return __shfl(sel, gbase + lown);
+            };
+            // dS_idx/dnu = sum of dx_t/dnu over the run of unclamped steps that ends at idx
+            int jlast = -1;      // last clamped step before idx (set by slope_at)
+            auto slope_at = [&](int idx) -> double {
+                jlast = -1;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    if (c == cown) sel = Sv[c];
                     const int t = tbase + c;
-                    const unsigned long long b = group_bits<LPS>(t < idx && (Sv[c] <= 0.0 || Sv[c] >= ag.em), gbase);
-                    if (b) { const int j = (63 - __clzll(b)) * NCH + c; jlast = j > jlast ? j : jlast; }
+                    const unsigned long long bts = group_bits<LPS>(t < idx && (Sv[c] <= 0.0 || Sv[c] >= ag.em), gbase);
+                    if (bts) { const int j = (63 - __clzll(bts)) * NCH + c; jlast = j > jlast ? j : jlast; }
                 }
-                sv = __shfl(sel, gbase + lown);
                 double part = 0.0;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const int t = tbase + c;
                     if (t > jlast && t <= idx) part += sg[c];
                 }
-                sl = group_sum<LPS>(part);
+                return group_sum<LPS>(part);
+            };
+            // S_idx is flat at nu: jump just past the nearest kink of the x_t in its run (jlast, idx] in direction dir.
+            // Any trial point is legitimate (the bracket keeps the search safe); this one has the right scale.
+            auto flat_jump = [&](int idx, double dir) -> double {
+                double best = INFINITY;                   // distance to the nearest kink ahead
+                if (!LINES) {
+                    const double det0 = a0 * a0 - gam * gam, iamb = 1.0 / (a0 - gam);
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        if (tbase + c > idx || tbase + c <= jlast) continue;
+                        const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
+                        const double rD0 = w * D0[c] - ag.mc - theta, rC0 = w * C0[c] - ag.mc + theta;
+                        const double bp = gam * ag.pm, ap = a0 * ag.pm;
+                        const double fD = (a0 * rD0 + gam * rC0) * iamb, fC = -(a0 * rC0 + gam * rD0) * iamb, dp = det0 * ag.pm * iamb;
+                        const double cand[12] = {rD0 - ap, rD0, -rC0, ap - rC0, rD0 + bp - ap, rD0 + bp, -rC0 - bp,
+                                                 ap - rC0 - bp, fD, fD - dp, fC, fC + dp};
+#pragma unroll
+                        for (int q = 0; q < 12; ++q) {
+                            const double d = (cand[q] - nu) * dir;
+                            if (d > 0.0) best = fmin(best, d);
+                        }
+                    }
+                }
+                best = group_min<LPS>(best);
+                if (best < INFINITY) return nu + dir * (best + 1e-9 * (1.0 + fabs(nu) + best));
+                const double tr = nu + dir * step;
+                step *= 4.0;
+                return tr;
             };
 
             bool classify = active && mode == 0;
             if (active && mode == 1) {
-                double sv, sl;
-                level_and_slope(vv, sv, sl);
-                const double res = sv - target;
+                const double res = level_at(vv) - target;
                 if (res < 0.0) lo = nu; else hi = nu;
                 bool conv = fabs(res) <= 1e-12 * (1.0 + ag.em) || rit >= 80;
                 double trial = nu;
                 if (!conv) {
+                    const double sl = slope_at(vv);
                     const bool both = lo > -INFINITY && hi < INFINITY;
-                    trial = sl > 0.0 ? nu - res / sl : NAN;
+                    if (sl > 0.0) {
+                        double r = __builtin_amdgcn_rcp(sl);
+                        r = r * (2.0 - sl * r);
+                        trial = nu - res * r;
+                    } else {
+                        trial = both ? 0.5 * (lo + hi) : flat_jump(vv, res < 0.0 ? 1.0 : -1.0);
+                    }
                     const bool forceBis = both && rit >= 6 && (rit & 1);
                     if (!(trial > lo && trial < hi) || forceBis) {
                         if (both) trial = 0.5 * (lo + hi);
@@ -413,8 +465,8 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const int t = tbase + c;
-                    const unsigned long long b = group_bits<LPS>(t <= k && t < T && (Sv[c] < -tol || Sv[c] > ag.em + tol), gbase);
-                    if (b) { const int j = (63 - __clzll(b)) * NCH + c; vnew = j > vnew ? j : vnew; }
+                    const unsigned long long bts = group_bits<LPS>(t <= k && t < T && (Sv[c] < -tol || Sv[c] > ag.em + tol), gbase);
+                    if (bts) { const int j = (63 - __clzll(bts)) * NCH + c; vnew = j > vnew ? j : vnew; }
                 }
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
@@ -424,16 +476,20 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
                 if (vnew < 0) {
                     k = -1;
                 } else {
-                    double sv, sl;
-                    level_and_slope(vnew, sv, sl);
+                    const double sv = level_at(vnew), sl = slope_at(vnew);
                     vv = vnew;
                     target = sv < 0.0 ? 0.0 : ag.em;
                     const double res = sv - target;
                     lo = -INFINITY; hi = INFINITY;
                     if (res < 0.0) lo = nu; else hi = nu;
                     step = 1.0 + fabs(nu);
-                    if (sl > 0.0) nu -= res / sl;
-                    else { nu = (res < 0.0) ? nu + step : nu - step; step *= 4.0; }
+                    if (sl > 0.0) {
+                        double r = __builtin_amdgcn_rcp(sl);
+                        r = r * (2.0 - sl * r);
+                        nu -= res * r;
+                    } else {
+                        nu = flat_jump(vnew, res < 0.0 ? 1.0 : -1.0);
+                    }
                     mode = 1;
                     rit = 0;
 #ifdef DOPF_STATS
@@ -501,11 +557,11 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
 
 bool sto_config_supported(int T, Launch *lc)
 {
-    // lane group x consecutive timesteps per lane; LPS <= 16 keeps every cross-lane step a DPP row op
+    // lane group x consecutive timesteps per lane; 3 timesteps per lane keeps the kernel at 2 waves/SIMD
     if (T <= 24) { lc->stoLPS = 8; lc->stoNCH = (T + 7) / 8; return true; }
     if (T <= 48) { lc->stoLPS = 16; lc->stoNCH = 3; return true; }
-    if (T <= 96) { lc->stoLPS = 16; lc->stoNCH = 6; return true; }
-    if (T <= 192) { lc->stoLPS = 32; lc->stoNCH = 6; return true; }
+    if (T <= 96) { lc->stoLPS = 32; lc->stoNCH = 3; return true; }
+    if (T <= 192) { lc->stoLPS = 64; lc->stoNCH = 3; return true; }
     if (T <= 384) { lc->stoLPS = 64; lc->stoNCH = 6; return true; }
     if (T <= 512) { lc->stoLPS = 64; lc->stoNCH = 8; return true; }
     return false;
@@ -523,9 +579,9 @@ void launch_sto_update(const DevView &v, const Launch &lc, hipStream_t s)
     if (v.nStoItems == 0) return;
 #define DOPF_CASE(LPS_, NCH_) if (lc.stoLPS == LPS_ && lc.stoNCH == NCH_) { launch_sto_t<LPS_, NCH_>(v, s); return; }
     DOPF_CASE(8, 1) DOPF_CASE(8, 2) DOPF_CASE(8, 3)
-    DOPF_CASE(16, 3) DOPF_CASE(16, 6)
-    DOPF_CASE(32, 3) DOPF_CASE(32, 6)
-    DOPF_CASE(64, 6) DOPF_CASE(64, 8)
+    DOPF_CASE(16, 3)
+    DOPF_CASE(32, 3)
+    DOPF_CASE(64, 3) DOPF_CASE(64, 6) DOPF_CASE(64, 8)
 #undef DOPF_CASE
 }
 
