@@ -1,9 +1,9 @@
 // dopf_api.hip — host side of libdopf_hip: the C ABI of include/dopf.h.
 //
 // One context = one GPU's shard of the agents + a replica of the O((N+L)T) consensus state.
-// An ADMM iteration is a short kernel chain on one stream (storage kernel forked onto a side
-// stream so it overlaps the bandwidth-bound generator kernel):
-//   [k_tables] -> { k_gen_update || k_sto_update } -> [k_slack] -> k_reduce -> (all-reduce) -> k_dual -> k_price
+// An ADMM iteration is a short kernel chain on one stream (with DOPF_F_OVERLAP_AGENTS the storage
+// kernel is forked onto a side stream so that it overlaps the bandwidth-bound generator kernel):
+//   [k_tables] -> k_gen_update -> k_sto_update -> [k_slack] -> k_reduce -> (all-reduce) -> k_dual -> k_price
 // dopf_iterate replays it from a captured hipGraph (UNROLL iterations per graph launch) so that the
 // loop runs without host round trips; convergence is tested on the device and freezes the state.
 #include <algorithm>
@@ -106,7 +106,7 @@ void enqueue_local(dopf_ctx *c)
 {
     const DevView &v = c->v;
     launch_tables(v, c->main);
-    const bool fork = v.nGenItems > 0 && v.nStoItems > 0 && !(c->q.flags & DOPF_F_SERIAL_AGENTS);
+    const bool fork = v.nGenItems > 0 && v.nStoItems > 0 && (c->q.flags & DOPF_F_OVERLAP_AGENTS);
     if (fork) {
         hipEventRecord(c->evFork, c->main);
         hipStreamWaitEvent(c->side, c->evFork, 0);
@@ -296,7 +296,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     st0.iteration = 1;                                      // admm.jl:29
     HIPTRY(hipMemcpyAsync(v.st, &st0, sizeof st0, hipMemcpyHostToDevice, c->main));
     // "no result yet" state: zeros everywhere, injection = -demand (helpers/results.jl:14-73)
-    launch_derive(v, c->main);
+    launch_derive(v, c->main, false);     // all-zero primal state: the consensus buffer is already zero
     HIPTRY(hipGetLastError());
     HIPTRY(hipStreamSynchronize(c->main));
     c->host_st = st0;
@@ -353,10 +353,10 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
     if (!c || !out || n_iters < 1 || n_iters > 4096) return fail(c, DOPF_E_INVALID, "bad argument");
     DeviceGuard guard(c->device);
     const DevView &v = c->v;
-    enum { E_T0, E_T1, E_G0, E_G1, E_S0, E_S1, E_K0, E_K1, E_R1, E_D1, E_N };
+    enum { E_T0, E_T1, E_G0, E_G1, E_S0, E_S1, E_K0, E_K1, E_R1, E_D1, E_X0, E_X1, E_N };
     std::vector<hipEvent_t> ev((size_t)n_iters * E_N);
     for (auto &e : ev) HIPCHK(c, hipEventCreate(&e));
-    const bool fork = v.nGenItems > 0 && v.nStoItems > 0 && !(c->q.flags & DOPF_F_SERIAL_AGENTS);
+    const bool fork = v.nGenItems > 0 && v.nStoItems > 0 && (c->q.flags & DOPF_F_OVERLAP_AGENTS);
     for (int i = 0; i < n_iters; ++i) {
         hipEvent_t *e = &ev[(size_t)i * E_N];
         hipEventRecord(e[E_T0], c->main);
@@ -378,6 +378,8 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
         hipEventRecord(e[E_R1], c->main);
         launch_dual(v, c->main);
         hipEventRecord(e[E_D1], c->main);
+        hipEventRecord(e[E_X0], c->main);
+        hipEventRecord(e[E_X1], c->main);
     }
     HIPCHK(c, hipGetLastError());
     int rc = read_status(c);
@@ -394,10 +396,11 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
         out->reduce_ms += ms(e[E_K1], e[E_R1]);
         out->dual_ms += ms(e[E_R1], e[E_D1]);
         out->iter_ms += ms(e[E_T0], e[E_D1]);
+        out->empty_ms += ms(e[E_X0], e[E_X1]);
     }
     const double inv = 1.0 / n_iters;
     out->tables_ms *= inv; out->gen_ms *= inv; out->sto_ms *= inv; out->slack_ms *= inv;
-    out->reduce_ms *= inv; out->dual_ms *= inv; out->iter_ms *= inv;
+    out->reduce_ms *= inv; out->dual_ms *= inv; out->iter_ms *= inv; out->empty_ms *= inv;
     out->iters = n_iters;
     for (auto &e : ev) hipEventDestroy(e);
     return DOPF_OK;
@@ -594,7 +597,7 @@ int dopf_set_state(dopf_ctx *c, const double *P, const double *D, const double *
     st.halt = (v.max_iters > 0 && iteration > v.max_iters);
     st.resbits[0] = st.resbits[1] = st.resbits[2] = 0;
     HIPCHK(c, hipMemcpy(v.st, &st, sizeof st, hipMemcpyHostToDevice));
-    launch_derive(v, c->main);
+    launch_derive(v, c->main, true);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->main));
     c->host_st = st;

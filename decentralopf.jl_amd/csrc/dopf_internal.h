@@ -84,6 +84,6 @@ void launch_tables(const DevView &v, hipStream_t s);
 void launch_slack(const DevView &v, hipStream_t s);
 void launch_reduce(const DevView &v, hipStream_t s);
 void launch_dual(const DevView &v, hipStream_t s);      // consensus -> duals, residuals, prices, status
-void launch_derive(const DevView &v, hipStream_t s);    // set_state: consensus -> inj/s/flow/price only
+void launch_derive(const DevView &v, hipStream_t s, bool from_primal);   // consensus -> inj/s/flow/price (no dual step)
 
 }  // namespace dopf

@@ -424,12 +424,14 @@ __global__ __launch_bounds__(256) void k_derive_level(DevView v)
     }
 }
 
-void launch_derive(const DevView &v, hipStream_t s)
+void launch_derive(const DevView &v, hipStream_t s, bool from_primal)
 {
     const size_t NT = (size_t)v.N * v.T, LT = (size_t)v.L * v.T;
     const size_t n1 = NT > LT ? NT : LT;
-    hipLaunchKernelGGL(k_derive_cons, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, v);
-    if (v.S > 0) hipLaunchKernelGGL(k_derive_level, dim3((unsigned)((v.S + 255) / 256)), dim3(256), 0, s, v);
+    if (from_primal) {        // serial over a node's agents: fine for tests / resume, not a hot path
+        hipLaunchKernelGGL(k_derive_cons, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, v);
+        if (v.S > 0) hipLaunchKernelGGL(k_derive_level, dim3((unsigned)((v.S + 255) / 256)), dim3(256), 0, s, v);
+    }
     hipLaunchKernelGGL(k_dual<false>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_price<false>, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, v);
 }

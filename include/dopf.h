@@ -95,7 +95,9 @@ typedef struct dopf_params {
 } dopf_params;
 
 #define DOPF_F_NO_GRAPH   1   /* launch kernels eagerly instead of through a captured hipGraph   */
-#define DOPF_F_SERIAL_AGENTS 2 /* storage kernel on the main stream (no fork/join side stream)    */
+#define DOPF_F_OVERLAP_AGENTS 2 /* storage kernel forked onto a side stream so it overlaps the generator
+                                   kernel (default: one stream, kernels back to back — the per-kernel
+                                   durations then mean the same in every tool)                        */
 
 /* Fill q with the reference's defaults (values above). */
 void dopf_default_params(dopf_params *q);
@@ -152,6 +154,7 @@ int dopf_set_state(dopf_ctx *ctx, const double *P, const double *D, const double
 typedef struct dopf_timing {
     double tables_ms, gen_ms, sto_ms, slack_ms, reduce_ms, dual_ms;  /* per-kernel averages     */
     double iter_ms;                                                  /* whole iteration, event to event */
+    double empty_ms;    /* an event pair with nothing between: the fixed cost inside every number above */
     int32_t iters;
 } dopf_timing;
 int dopf_iterate_timed(dopf_ctx *ctx, int32_t n_iters, dopf_timing *out);

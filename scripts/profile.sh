@@ -1,0 +1,38 @@
+#!/bin/bash
+# rocprofv3 profile of bench.py for one workload; summaries land in gpurun_out/prof_<workload>/ and are
+# copied into profiles/ by hand (profiles/ is tracked, gpurun_out/ is scratch).
+#   pass 1: --kernel-trace --stats          per-kernel durations (must agree with bench.py's HIP-event numbers)
+#   pass 2: --pmc FETCH_SIZE                HBM read traffic   } separate passes, no tracing mixed in
+#   pass 3: --pmc WRITE_SIZE                HBM write traffic  } (MI355X_MICROARCH.md, rocprofv3 PMC slots)
+set -e
+W=${1:-config2}
+ROOT=$GRAFT_REPO_ROOT
+OUT=$ROOT/gpurun_out/prof_$W
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+cd $ROOT
+ARGS="bench.py --workload $W --no-cpu-baseline --steps 100 --warmup 16 --timed-iters 16"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.json 2> $OUT/fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.json 2> $OUT/write.err
+python3 - <<PY
+import csv, glob, json, collections
+out = {}
+for f in glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    out["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs") if k in r} for r in rows]
+    import shutil; shutil.copy(f, "$OUT/kernel_stats.csv")
+pmc = {}
+for name in ("fetch", "write"):
+    for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % name, recursive=True):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in agg.items():
+            pmc.setdefault(k, {})[c] = {"mean": sum(v) / len(v), "n": len(v)}
+out["pmc"] = pmc
+out["bench_line"] = json.loads(open("$OUT/trace.json").read().strip().splitlines()[-1])
+json.dump(out, open("$OUT/summary.json", "w"), indent=1)
+for r in out.get("kernel_stats", []): print(r)
+for k, d in pmc.items(): print(k, d)
+PY

@@ -21,7 +21,7 @@ def test_hip_follows_reference_dump(hip_api, three_node, golden, name):
     assert e.solver_failures() == 0
 
 
-@pytest.mark.parametrize("flags", [0, _capi.F_NO_GRAPH, _capi.F_SERIAL_AGENTS], ids=["graph", "eager", "one-stream"])
+@pytest.mark.parametrize("flags", [0, _capi.F_NO_GRAPH, _capi.F_OVERLAP_AGENTS], ids=["graph", "eager", "two-streams"])
 def test_hip_three_node_converges_like_the_thesis(hip_api, three_node, thesis, flags):
     e = make_engine(hip_api, three_node[4], flags=flags)
     done, conv = e.iterate(5000)                                          # one call, stop test on the device
@@ -131,7 +131,7 @@ def test_hip_is_bitwise_reproducible(hip_api):
     """Fixed-order reductions: two runs give identical bits, with and without the graph."""
     pp = synth.synthetic_case(3000, 300, 24, seed=31)
     outs = []
-    for flags in (0, 0, _capi.F_NO_GRAPH, _capi.F_SERIAL_AGENTS):
+    for flags in (0, 0, _capi.F_NO_GRAPH, _capi.F_OVERLAP_AGENTS):
         e = make_engine(hip_api, pp, eps=0.0, gamma=1.0 / 3300, flags=flags)
         e.iterate(40)
         outs.append(state_of(e))
