@@ -128,15 +128,15 @@ def main():
         sync = lambda: eng.sync()
     else:
         from decentralopf_jl_amd.sharded import ShardedADMM
-        # ShardedADMM shards a global problem; here each rank already holds its own slice
-        sh = ShardedADMM.__new__(ShardedADMM)
-        sh.rank, sh.world, sh.problem, sh.shard = rank, world, pp, pp
-        kw = dict(gamma=gamma, eps=0.0, n_agents_global=A_global, device=local_rank,
-                  stream=torch.cuda.current_stream(local_rank).cuda_stream)
-        sh.engine = _capi.Engine(_capi.hip_api(), params=_capi.default_params(**kw), **pp.engine_kwargs())
-        sh._tensor = torch.zeros(sh.engine.consensus_size(), dtype=torch.float64, device="cuda")
-        sh.engine.bind_consensus(sh._tensor.data_ptr())
-        sh._all_reduce = lambda: dist.all_reduce(sh._tensor, op=dist.ReduceOp.SUM)
+        # every rank already holds its own grid: a 1-way "shard" of its local problem, global agent count
+        # passed explicitly; the all-reduce runs over all ranks on the engine's own stream
+        sh = ShardedADMM(pp, 0, 1, gamma=gamma, eps=0.0, device=local_rank, n_agents_global_override=A_global)
+        st, tens = sh.stream, sh._tensor
+
+        def _all_reduce():
+            with torch.cuda.stream(st):
+                dist.all_reduce(tens, op=dist.ReduceOp.SUM)
+        sh._all_reduce = _all_reduce
         eng = sh.engine
         step = lambda n: sh.step(n)
         sync = lambda: sh.sync()

@@ -35,11 +35,11 @@ def host_consensus_view(engine: _capi.Engine) -> np.ndarray:
 class ShardedADMM:
     def __init__(self, problem: PackedProblem, rank: int, world: int, *, api: Optional[_capi.CApi] = None,
                  all_reduce: Optional[Callable[[], None]] = None, mode: Optional[int] = None,
-                 device: Optional[int] = None, **params):
+                 device: Optional[int] = None, n_agents_global_override: Optional[int] = None, **params):
         self.rank, self.world = rank, world
         self.problem = problem
         self.shard = problem.shard(rank, world)
-        self.n_agents_global = problem.G + problem.S
+        self.n_agents_global = n_agents_global_override or (problem.G + problem.S)
         self._tensor = None
         kw = dict(params)
         kw["n_agents_global"] = self.n_agents_global
@@ -48,17 +48,24 @@ class ShardedADMM:
             import torch.distributed as dist
             if device is None:
                 device = torch.cuda.current_device()
+            dev = torch.device("cuda", device)
+            # one dedicated (non-null) stream carries the kernels AND, as torch's current stream, orders
+            # the RCCL all-reduce between dopf_local_update and dopf_apply_consensus
+            self.stream = torch.cuda.Stream(device=dev)
             kw["device"] = device
-            kw["stream"] = torch.cuda.current_stream(device).cuda_stream
+            kw["stream"] = self.stream.cuda_stream
             self.engine = _capi.Engine(_capi.hip_api(), params=_capi.default_params(**kw),
                                        **self.shard.engine_kwargs())
-            self._tensor = torch.zeros(self.engine.consensus_size(), dtype=torch.float64,
-                                       device=torch.device("cuda", device))
+            self._tensor = torch.zeros(self.engine.consensus_size(), dtype=torch.float64, device=dev)
+            torch.cuda.synchronize(dev)
             self.engine.bind_consensus(self._tensor.data_ptr())
             if all_reduce is None:
                 if world > 1:
-                    t = self._tensor
-                    all_reduce = lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                    t, st = self._tensor, self.stream
+
+                    def all_reduce():
+                        with torch.cuda.stream(st):
+                            dist.all_reduce(t, op=dist.ReduceOp.SUM)
                 else:
                     all_reduce = lambda: None
         else:

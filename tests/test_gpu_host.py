@@ -34,3 +34,38 @@ def test_sharded_driver_world1_on_hip(hip_api):
     a, b = state_of(sh.engine), state_of(ref)
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_sharded_driver_with_rccl_allreduce_world1(hip_api):
+    """A one-rank nccl (= RCCL) process group: the all-reduce really runs between dopf_local_update and
+    dopf_apply_consensus on the engine's stream; results must equal the plain engine bit for bit."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from helpers import make_engine, state_of
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        pp = synth.synthetic_case(400, 40, 24, N=3, L=3, seed=6, fmax_factor=0.8, fmax_min=5)
+        g = 0.01
+        sh = pkg.ShardedADMM(pp, 0, 1, eps=0.0, gamma=g)
+        tens, st = sh._tensor, sh.stream
+
+        def all_reduce():
+            with torch.cuda.stream(st):
+                dist.all_reduce(tens, op=dist.ReduceOp.SUM)
+        sh._all_reduce = all_reduce
+        sh.step(20)
+        assert sh.sync() == (21, False)
+        ref = make_engine(hip_api, pp, eps=0.0, gamma=g)
+        ref.iterate(20)
+        a, b = state_of(sh.engine), state_of(ref)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+    finally:
+        dist.destroy_process_group()
