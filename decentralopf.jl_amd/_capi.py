@@ -50,6 +50,7 @@ class DopfTiming(C.Structure):
 
 F_NO_GRAPH = 1
 F_OVERLAP_AGENTS = 2
+F_NO_WARM_START = 4
 
 
 class DopfError(RuntimeError):

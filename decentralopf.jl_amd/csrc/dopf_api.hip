@@ -223,6 +223,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     v.max_iters = q->max_iters;
     const int A = q->n_agents_global > 0 ? q->n_agents_global : G + S;
     v.invA = A > 0 ? 1.0 / (double)A : 0.0;
+    v.use_warm = (L == 0 && S > 0 && lc.stoNCH <= 3 && !(q->flags & DOPF_F_NO_WARM_START)) ? 1 : 0;
     v.genTT = std::min(T, 512);
     v.genR = 512 / v.genTT;
 
@@ -285,6 +286,9 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     }
     TRY(dev_alloc(c, &v.part_ginj, (size_t)v.nGenItems * T)); TRY(dev_alloc(c, &v.part_gcost, v.nGenItems));
     TRY(dev_alloc(c, &v.part_sinj, (size_t)v.nStoItems * T)); TRY(dev_alloc(c, &v.part_scost, v.nStoItems));
+    TRY(dev_alloc(c, &v.part_sinj_w, (size_t)v.nStoItems * T)); TRY(dev_alloc(c, &v.part_scost_w, v.nStoItems));
+    TRY(dev_alloc(c, &v.nu_prev, (size_t)S * T)); TRY(dev_alloc(c, &v.nu_valid, S)); TRY(dev_alloc(c, &v.sto_fail, S));
+    TRY(dev_alloc(c, &v.item_fail, v.nStoItems));
     TRY(dev_alloc(c, &v.part2, (size_t)N * v.reduceRB * T)); TRY(dev_alloc(c, &v.part2_cost, v.reduceRB));
     TRY(dev_alloc(c, &v.reduce_ticket, N));
     double *cons = nullptr;
@@ -590,6 +594,7 @@ int dopf_set_state(dopf_ctx *c, const double *P, const double *D, const double *
     if ((rc = up(v.lam, lambda, v.T))) return rc;
     if ((rc = up(v.mu, mu, LT))) return rc;
     if ((rc = up(v.rho, rho, LT))) return rc;
+    if (v.S > 0) HIPCHK(c, hipMemset(v.nu_valid, 0, sizeof(int) * v.S));   // stored prices no longer match the state
     Status st{};
     HIPCHK(c, hipMemcpy(&st, v.st, sizeof st, hipMemcpyDeviceToHost));
     st.iteration = iteration;
@@ -621,13 +626,22 @@ int dopf_debug_table(dopf_ctx *c, int32_t n, int32_t t, double *beta, double *ps
 }
 
 // diagnostics (DOPF_STATS builds): cumulative storage-kernel counters {scans, wave loop trips, events}
-int dopf_debug_stats(dopf_ctx *c, uint64_t *out3)
+int dopf_debug_stats(dopf_ctx *c, uint64_t *out3 /* 9 values */)
 {
     if (!c || !out3) return DOPF_E_INVALID;
     DeviceGuard guard(c->device);
     int rc = read_status(c);
     if (rc) return rc;
     out3[0] = c->host_st.dbg_scans; out3[1] = c->host_st.dbg_wave_loops; out3[2] = c->host_st.dbg_events;
+    {   // warm-start kernel, LAST iteration: storages it solved / left to the scan kernel
+        std::vector<int> f(c->v.nStoItems);
+        if (!f.empty()) HIPCHK(c, hipMemcpy(f.data(), c->v.item_fail, f.size() * sizeof(int), hipMemcpyDeviceToHost));
+        uint64_t nf = 0;
+        for (int x : f) nf += (uint64_t)x;
+        out3[4] = c->v.use_warm ? nf : (uint64_t)c->v.S;
+        out3[3] = (uint64_t)c->v.S - out3[4];
+    }
+    for (int i = 0; i < 4; ++i) out3[5 + i] = c->host_st.dbg_reason[i];
     return DOPF_OK;
 }
 

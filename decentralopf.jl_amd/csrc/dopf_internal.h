@@ -34,6 +34,7 @@ struct Status {
     int iters_total;        // iterations computed since creation
     unsigned long long solver_fail;
     unsigned long long dbg_scans, dbg_wave_loops, dbg_events;   // storage kernel statistics (DOPF_STATS builds)
+    unsigned long long dbg_reason[4];                           // DOPF_STATS: no prices / Newton / level / sign
     unsigned long long resbits[3];   // running max of |dual change| as bit patterns (>= 0 doubles)
     double res[3];          // lambda / mu / rho residual inf-norms of the last checked iteration
     double total_cost;
@@ -44,6 +45,7 @@ struct DevView {
     int nGenItems, nStoItems;
     int genTT, genR;                // generator block tiling: TT = min(T, 512) timesteps x R agents
     int reduceRB;                   // reduce blocks per node (two-level fixed-order sum)
+    int use_warm;                   // storage warm-start kernel runs first; the scan kernel serves its failures
     int max_iters;
     double gamma, w_flow, w_prox, eps, mask_thr, invA;
     // problem (read-only)
@@ -63,7 +65,10 @@ struct DevView {
     int *tb_m;
     // partials
     double *part_ginj, *part_gcost;                 // [item*T + t], [item]
-    double *part_sinj, *part_scost;
+    double *part_sinj, *part_scost;                 // storage scan kernel, per item
+    double *part_sinj_w, *part_scost_w;             // storage warm-start kernel, per item
+    double *nu_prev;                                // [t + T*s] price of stored energy of the last solve
+    int *nu_valid, *sto_fail, *item_fail;           // [s], [s], [item] (= storages of the item the warm start left over)
     double *part_U, *part_K;                        // [(n*T + t)*L + l]
     double *part2, *part2_cost;                     // [(n*RB + rb)*T + t], [rb]
     int *reduce_ticket;                             // [n]

@@ -256,6 +256,11 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
     const int gbase = lane & ~(LPS - 1);
     const Item it = v.sto_items[blockIdx.x];
     const int T = v.T, N = v.N;
+    if (!LINES && v.use_warm && v.item_fail[blockIdx.x] == 0) {      // the warm-start kernel solved this whole item
+        for (int t = tid; t < T; t += 256) v.part_sinj[(size_t)blockIdx.x * T + t] = 0.0;
+        if (tid == 0) v.part_scost[blockIdx.x] = 0.0;
+        return;
+    }
     const double w = v.w_prox, gam = v.gamma;
     const double a0 = w + gam, ia0 = 1.0 / a0, idet0 = 1.0 / (a0 * a0 - gam * gam), s20 = 2.0 / (a0 + gam);
     const int tbase = li * NCH;
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
 
     for (int rep = 0; rep < nRep; ++rep) {
         const int s = it.a0 + rep * NG + grp;
-        const bool live = s < it.a1;
+        const bool live = s < it.a1 && (LINES || !v.use_warm || v.sto_fail[s] != 0);
         StoAgent ag;
         ag.mc = live ? v.sto_mc[s] : 0.0;
         ag.pm = live ? v.sto_pmax[s] : 0.0;
@@ -508,6 +513,7 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
             if (live && tbase + c < T) eval(c, nuf[c], Dn[c], Cn[c], s1);
             run += Cn[c] - Dn[c];
         }
+        if (!LINES && live && li == 0) v.nu_valid[s] = 1;
         const double incl = scan_sum<LPS>(run, lane);
         const double incl_prev = prev_lane<LPS>(incl);     // DPP: every lane must execute it (no ?: around it)
         double ev = li == 0 ? 0.0 : incl_prev;
@@ -520,6 +526,7 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
                 v.C[e] = Cn[c];
                 v.E[e] = ev;
                 if (LINES) v.dltS[e] = (Dn[c] - Cn[c]) - (D0[c] - C0[c]);
+                else v.nu_prev[e] = nuf[c];
                 accQ[c] += Dn[c] - Cn[c];
                 accCost += ag.mc * (Dn[c] + Cn[c]);
             }
@@ -555,6 +562,346 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// storages, warm start: re-solve on the previous iteration's structure, accept only with a certificate
+// ------------------------------------------------------------------------------------------------
+//
+// Near convergence the SET of timesteps at which a storage is full or empty does not change from one
+// ADMM iteration to the next. This kernel takes that set from the previous level trajectory, gives every
+// segment between two contacts one price and solves sum_{t in seg} x_t(nu) = level change of the segment
+// for all segments at once (segmented Newton: a segmented scan supplies the sums, LDS hands the new
+// price back to the segment's timesteps), then CHECKS the KKT conditions of the storage QP:
+//   levels within [0, emax]; at a contact at 0 the price may only fall going forward, at emax only rise;
+//   the open last segment has price 0 (nu_{T+1} = 0).
+// The QP is strictly convex in (D, C), so a point that passes is THE minimiser — whatever produced the
+// guess. Storages that fail (structure changed, Newton stalled, no previous prices) are left untouched
+// and flagged for the scan kernel. Cost is independent of the number of contacts.
+
+// inclusive segmented scan of (a, b) over the lanes of each group; f = "a segment starts in this lane"
+template <int LPS>
+__device__ __forceinline__ void seg_scan2(int &f, double &a, double &b, int lane)
+{
+    const int r = lane & ((LPS < 16 ? LPS : 16) - 1);
+#define DOPF_SEG_STEP(CTRL, RM, COND)                                                        \
+    {                                                                                        \
+        const int pf = __builtin_amdgcn_update_dpp(f, f, CTRL, RM, 0xF, false);              \
+        const double pa = dppd<CTRL, RM>(a, a), pb = dppd<CTRL, RM>(b, b);                   \
+        if (COND) { if (!f) { a += pa; b += pb; } f |= pf; }                                 \
+    }
+    DOPF_SEG_STEP(0x111, 0xF, r >= 1)
+    if (LPS >= 4) DOPF_SEG_STEP(0x112, 0xF, r >= 2)
+    if (LPS >= 8) DOPF_SEG_STEP(0x114, 0xF, r >= 4)
+    if (LPS >= 16) DOPF_SEG_STEP(0x118, 0xF, r >= 8)
+    if (LPS >= 32) DOPF_SEG_STEP(0x142, 0xA, lane & 16)
+    if (LPS >= 64) DOPF_SEG_STEP(0x143, 0xC, lane & 32)
+#undef DOPF_SEG_STEP
+}
+
+template <int LPS>
+__device__ __forceinline__ double group_max(double x)
+{
+    if (LPS >= 2) x = fmax(x, dppd<0xB1, 0xF>(x, x));
+    if (LPS >= 4) x = fmax(x, dppd<0x4E, 0xF>(x, x));
+    if (LPS >= 8) x = fmax(x, dppd<0x141, 0xF>(x, x));
+    if (LPS >= 16) x = fmax(x, dppd<0x140, 0xF>(x, x));
+    if (LPS >= 32) x = fmax(x, __shfl_xor(x, 16));
+    if (LPS >= 64) x = fmax(x, __shfl_xor(x, 32));
+    return x;
+}
+
+// suffix (right-to-left) inclusive scan of clamp maps x -> clamp(x, lo, hi) over the lanes of each group:
+// lane l ends up with M_l o M_{l+1} o ... o M_last (the right-most map is applied first)
+template <int LPS>
+__device__ __forceinline__ void scan_clamps_rev(double &lo, double &hi, int lane)
+{
+    constexpr int RL = LPS < 16 ? LPS : 16;
+    const int r = lane & (RL - 1);
+#define DOPF_REV_STEP(CTRL, D)                                                       \
+    {                                                                                \
+        const double glo = dppd<CTRL, 0xF>(lo, lo), ghi = dppd<CTRL, 0xF>(hi, hi);   \
+        if (r + D < RL) { const double nlo = clampd(glo, lo, hi), nhi = clampd(ghi, lo, hi); lo = nlo; hi = nhi; } \
+    }
+    DOPF_REV_STEP(0x101, 1)                     // row_shl:1
+    if (LPS >= 4) DOPF_REV_STEP(0x102, 2)
+    if (LPS >= 8) DOPF_REV_STEP(0x104, 4)
+    if (LPS >= 16) DOPF_REV_STEP(0x108, 8)
+#undef DOPF_REV_STEP
+    if (LPS >= 32) {                            // rows 0, 2 take the whole of the next row (its lane 0)
+        const double glo = __shfl(lo, (lane | 15) + 1), ghi = __shfl(hi, (lane | 15) + 1);
+        if ((lane & 16) == 0) { const double nlo = clampd(glo, lo, hi), nhi = clampd(ghi, lo, hi); lo = nlo; hi = nhi; }
+    }
+    if (LPS >= 64) {                            // rows 0, 1 take rows 2-3 (lane 32)
+        const double glo = __shfl(lo, 32), ghi = __shfl(hi, 32);
+        if ((lane & 32) == 0) { const double nlo = clampd(glo, lo, hi), nhi = clampd(ghi, lo, hi); lo = nlo; hi = nhi; }
+    }
+}
+
+// value of the next lane of the group (garbage for the group's last lane: caller masks it)
+template <int LPS>
+__device__ __forceinline__ double next_lane(double x)
+{
+    if (LPS <= 16) return dppd<0x101, 0xF>(x, x);      // row_shl:1
+    return dppd<0x130, 0xF>(x, x);                     // wave_shl:1
+}
+
+template <int LPS, int NCH>
+__global__ __launch_bounds__(256) void k_sto_warm(DevView v)
+{
+    if (v.st->halt) return;
+    constexpr int NG = 256 / LPS, TP = LPS * NCH;
+    __shared__ double red[NG * TP];          // also nuL during the solve
+    __shared__ double baseL[NG * TP];
+    __shared__ int keyL[NG * TP];
+    __shared__ double redc[256];
+    const int tid = threadIdx.x, lane = tid & 63, li = tid & (LPS - 1), grp = tid / LPS;
+    const Item it = v.sto_items[blockIdx.x];
+    const int T = v.T, N = v.N;
+    const double w = v.w_prox, gam = v.gamma;
+    const double a0 = w + gam, ia0 = 1.0 / a0, idet0 = 1.0 / (a0 * a0 - gam * gam), s20 = 2.0 / (a0 + gam);
+    const int tbase = li * NCH;
+    double *nuL = red + grp * TP, *base = baseL + grp * TP;
+    int *key = keyL + grp * TP;
+
+    double th0[NCH], accQ[NCH];
+    double accCost = 0.0;
+    int anyFail = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int t = tbase + c;
+        accQ[c] = 0.0;
+        th0[c] = t < T ? v.price[it.node + N * t] + gam * v.s[t] : 0.0;
+    }
+    const int nRep = (it.a1 - it.a0 + NG - 1) / NG;
+    for (int rep = 0; rep < nRep; ++rep) {
+        const int s = it.a0 + rep * NG + grp;
+        const bool live = s < it.a1;
+        const double mc = live ? v.sto_mc[s] : 0.0, pm = live ? v.sto_pmax[s] : 0.0, em = live ? v.sto_emax[s] : 0.0;
+        bool good = live && v.nu_valid[s] != 0;
+        double D0[NCH], C0[NCH], nuv[NCH];
+        double run = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int t = tbase + c;
+            const bool ok = live && t < T;
+            const size_t e = (size_t)s * T + (ok ? t : 0);
+            D0[c] = ok ? v.D[e] : 0.0;
+            C0[c] = ok ? v.C[e] : 0.0;
+            nuv[c] = ok ? v.nu_prev[e] : 0.0;
+            run += C0[c] - D0[c];
+        }
+        // previous level trajectory -> contacts -> segment ends
+        const double inclE = scan_sum<LPS>(run, lane);
+        const double prevE = prev_lane<LPS>(inclE);
+        double eo = li == 0 ? 0.0 : prevE;
+        const double tolc = 1e-9 * (1.0 + em), tolE = 1e-11 * (1.0 + em), tolr = 1e-12 * (1.0 + em);
+        int kind[NCH];                       // 0 free, 1 empty, 2 full
+        bool isend[NCH];
+        double tgt[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int t = tbase + c;
+            eo += C0[c] - D0[c];
+            kind[c] = t < T ? (eo <= tolc ? 1 : (eo >= em - tolc ? 2 : 0)) : 0;
+            isend[c] = t < T && (kind[c] != 0 || t == T - 1);
+            tgt[c] = kind[c] == 2 ? em : 0.0;
+            key[t] = isend[c] ? t : (t >= T ? T - 1 : 0x3fffffff);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int d = 1; d < TP; d <<= 1) {     // next segment end at or after t (pointer jumping in LDS)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int t = tbase + c;
+                if (t + d < TP) { const int o = key[t + d], m0 = key[t]; key[t] = o < m0 ? o : m0; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        int send[NCH];
+        bool st[NCH];
+        // info of the step before this lane's first step: target level if it is a segment end, else -1
+        const double lastInfo = isend[NCH - 1] ? tgt[NCH - 1] : -1.0;
+        const double plInfo = prev_lane<LPS>(lastInfo);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int t = tbase + c;
+            send[c] = key[t < TP ? t : TP - 1];
+            double pinfo;
+            if (c == 0) pinfo = li == 0 ? 0.0 : plInfo;
+            else pinfo = isend[c - 1] ? tgt[c - 1] : -1.0;
+            st[c] = t < T && pinfo >= 0.0;
+            if (st[c]) base[send[c]] = pinfo;                  // level at which this segment starts
+            if (isend[c]) nuL[t] = kind[c] != 0 ? nuv[c] : 0.0; // one price per segment; open last segment: 0
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) nuv[c] = (tbase + c < T) ? nuL[send[c]] : 0.0;
+
+        // ---- segmented Newton ---------------------------------------------------------------------
+        double Dv[NCH], Cv[NCH], px[NCH];
+        bool conv = false;
+        for (int itn = 0; itn < 8; ++itn) {
+            double sg[NCH], ps[NCH];
+            int f = 0;
+            double rx = 0.0, rs = 0.0;
+            bool seen[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int t = tbase + c;
+                double dd = 0.0, cc = 0.0, s1 = 0.0;
+                if (t < T) {
+                    const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
+                    box2(a0, gam, ia0, idet0, s20, w * D0[c] - mc - theta - nuv[c], w * C0[c] - mc + theta + nuv[c], pm, dd, cc, s1);
+                }
+                Dv[c] = dd; Cv[c] = cc; sg[c] = s1;
+                if (st[c]) { rx = 0.0; rs = 0.0; f = 1; }
+                rx += cc - dd; rs += s1;
+                px[c] = rx; ps[c] = rs;
+                seen[c] = f != 0;
+            }
+            int fl = f;
+            double ax = rx, as = rs;
+            seg_scan2<LPS>(fl, ax, as, lane);
+            double cx = prev_lane<LPS>(ax), cs = prev_lane<LPS>(as);
+            if (li == 0) { cx = 0.0; cs = 0.0; }
+            double worst = 0.0;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int t = tbase + c;
+                if (!seen[c]) { px[c] += cx; ps[c] += cs; }
+                if (isend[c] && kind[c] != 0) {
+                    const double r = base[t] + px[c] - tgt[c];
+                    const double ar = fabs(r);
+                    if (ar > tolr) {
+                        if (ps[c] > 0.0) nuL[t] = nuv[c] - r / ps[c];
+                        else worst = INFINITY;            // flat piece: leave it to the scan kernel
+                    }
+                    worst = fmax(worst, ar);
+                }
+            }
+            worst = group_max<LPS>(worst);
+            if (worst <= tolr) { conv = true; }
+            if (!(worst < INFINITY)) { conv = false; }
+            // every group in the wave runs the same number of rounds (DPP scans need all lanes)
+            if (__all(conv || !(worst < INFINITY) || !good)) break;
+            __builtin_amdgcn_wave_barrier();
+            if (!conv) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+                    if (tbase + c < T) nuv[c] = nuL[send[c]];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#ifdef DOPF_STATS
+        if (live && li == 0 && !good) atomicAdd(&v.st->dbg_reason[0], 1ull);
+        else if (live && li == 0 && !conv) atomicAdd(&v.st->dbg_reason[1], 1ull);
+#endif
+        good = good && conv;
+
+        // ---- certificate: levels inside the band, price jumps have the right sign ----------------------
+        // A contact step that is a segment of its own with zero net charge (the storage idles on a bound)
+        // accepts every price of its dead band [rD0, -rC0]; all other segment prices are points. Prices
+        // are then chosen right to left, nu_e = clamp(nu_next, band_e) starting from nu_{T+1} = 0 — the
+        // choice that satisfies the sign condition at e whenever any does — with one suffix scan of
+        // clamp maps, and the sign conditions are checked on that choice.
+        bool okk = true;
+#ifdef DOPF_STATS
+        bool okLevel = true;
+#endif
+        double Ev[NCH], mlo[NCH], mhi[NCH];
+        double alo = -INFINITY, ahi = INFINITY;              // this lane's maps, composed right to left
+#pragma unroll
+        for (int c = NCH - 1; c >= 0; --c) {
+            const int t = tbase + c;
+            mlo[c] = -INFINITY; mhi[c] = INFINITY;
+            Ev[c] = 0.0;
+            if (t < T) {
+                Ev[c] = base[send[c]] + px[c];
+                if (Ev[c] < -tolE || Ev[c] > em + tolE) {
+                    okk = false;
+#ifdef DOPF_STATS
+                    okLevel = false;
+#endif
+                }
+                if (isend[c]) {
+                    mlo[c] = mhi[c] = kind[c] != 0 ? nuv[c] : 0.0;
+                    if (kind[c] != 0 && st[c] && base[t] == tgt[c]) {
+                        const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
+                        const double rD0 = w * D0[c] - mc - theta, rC0 = w * C0[c] - mc + theta;
+                        if (rD0 <= -rC0 && nuv[c] >= rD0 - 1e-9 && nuv[c] <= -rC0 + 1e-9) { mlo[c] = rD0; mhi[c] = -rC0; }
+                    }
+                }
+            }
+            const double nlo = clampd(alo, mlo[c], mhi[c]), nhi = clampd(ahi, mlo[c], mhi[c]);   // M_c o (maps to the right)
+            alo = nlo; ahi = nhi;
+        }
+        scan_clamps_rev<LPS>(alo, ahi, lane);
+        // price arriving from the right of this lane: (lanes to the right)(0)
+        const double rightv = next_lane<LPS>(clampd(0.0, alo, ahi));
+        double val = li == LPS - 1 ? 0.0 : rightv;
+#pragma unroll
+        for (int c = NCH - 1; c >= 0; --c) {
+            const int t = tbase + c;
+            const double vin = val;
+            val = clampd(val, mlo[c], mhi[c]);
+            if (t < T && isend[c] && kind[c] != 0) {
+                const double tn = 1e-10 * (1.0 + fabs(val));
+                if (kind[c] == 1 && vin > val + tn) okk = false;      // empty: price may only fall going forward
+                if (kind[c] == 2 && vin < val - tn) okk = false;      // full: price may only rise
+                nuv[c] = val;                                          // (moves only inside a dead band)
+            }
+        }
+#ifdef DOPF_STATS
+        {
+            const bool lv = group_bits<LPS>(!okLevel, lane & ~(LPS - 1)) != 0ull, an = group_bits<LPS>(!okk, lane & ~(LPS - 1)) != 0ull;
+            if (live && li == 0 && good && lv) atomicAdd(&v.st->dbg_reason[2], 1ull);
+            else if (live && li == 0 && good && an) atomicAdd(&v.st->dbg_reason[3], 1ull);
+        }
+#endif
+        good = good && (group_bits<LPS>(!okk, lane & ~(LPS - 1)) == 0ull);
+
+        if (live && li == 0) v.sto_fail[s] = good ? 0 : 1;
+        if (live && !good && li == 0) anyFail += 1;
+        if (good) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int t = tbase + c;
+                if (t < T) {
+                    const size_t e = (size_t)s * T + t;
+                    v.D[e] = Dv[c];
+                    v.C[e] = Cv[c];
+                    v.E[e] = Ev[c];
+                    v.nu_prev[e] = nuv[c];
+                    accQ[c] += Dv[c] - Cv[c];
+                    accCost += mc * (Dv[c] + Cv[c]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // fixed-order block reduction of the per-timestep sums over the NG groups
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) red[(grp * LPS + li) * NCH + c] = accQ[c];
+    redc[tid] = accCost;
+    const int blockFail = __syncthreads_count(anyFail);      // storages of this item left to the scan kernel
+    if (grp == 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int t = tbase + c;
+            if (t < T) {
+                double sum = 0.0;
+                for (int g2 = 0; g2 < NG; ++g2) sum += red[(g2 * LPS + li) * NCH + c];
+                v.part_sinj_w[(size_t)blockIdx.x * T + t] = sum;
+            }
+        }
+    }
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if (tid < sft) redc[tid] += redc[tid + sft];
+        __syncthreads();
+    }
+    if (tid == 0) { v.part_scost_w[blockIdx.x] = redc[0]; v.item_fail[blockIdx.x] = blockFail; }
+}
+
 bool sto_config_supported(int T, Launch *lc)
 {
     // lane group x consecutive timesteps per lane; 3 timesteps per lane keeps the kernel at 2 waves/SIMD
@@ -570,6 +917,7 @@ bool sto_config_supported(int T, Launch *lc)
 template <int LPS, int NCH>
 static void launch_sto_t(const DevView &v, hipStream_t s)
 {
+    if (v.use_warm) hipLaunchKernelGGL((k_sto_warm<LPS, (NCH <= 3 ? NCH : 3)>), dim3(v.nStoItems), dim3(256), 0, s, v);
     if (v.L > 0) hipLaunchKernelGGL((k_sto_update<LPS, NCH, true>), dim3(v.nStoItems), dim3(256), 0, s, v);
     else hipLaunchKernelGGL((k_sto_update<LPS, NCH, false>), dim3(v.nStoItems), dim3(256), 0, s, v);
 }

@@ -230,7 +230,8 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
             if (r < R && t < T) {
 #pragma unroll 4
                 for (int i = i0 + r; i < i1; i += R)
-                    acc += i < ngi ? v.part_ginj[(size_t)(g0 + i) * T + t] : v.part_sinj[(size_t)(s0 + i - ngi) * T + t];
+                    acc += i < ngi ? v.part_ginj[(size_t)(g0 + i) * T + t]
+                                   : v.part_sinj[(size_t)(s0 + i - ngi) * T + t] + v.part_sinj_w[(size_t)(s0 + i - ngi) * T + t];
             }
             __syncthreads();
             red[tid] = acc;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
             const int nc = v.nGenItems + v.nStoItems, cper = (nc + RB - 1) / RB;
             const int c0 = rb * cper, c1 = min(nc, c0 + cper);
             double c = 0.0;
-            for (int i = c0 + tid; i < c1; i += 256) c += i < v.nGenItems ? v.part_gcost[i] : v.part_scost[i - v.nGenItems];
+            for (int i = c0 + tid; i < c1; i += 256) c += i < v.nGenItems ? v.part_gcost[i] : v.part_scost[i - v.nGenItems] + v.part_scost_w[i - v.nGenItems];
             c = block_sum256(c, red);
             if (tid == 0) v.part2_cost[rb] = c;
         }
