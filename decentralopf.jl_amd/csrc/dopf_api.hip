@@ -259,7 +259,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         // level-1 reduce blocks per node: ~16 items per block, at most 64 (and N*RB blocks in total)
         int max_items = 1;
         for (int n = 0; n < N; ++n) max_items = std::max(max_items, (ngib[n + 1] - ngib[n]) + (nsib[n + 1] - nsib[n]));
-        v.reduceRB = std::max(1, std::min(64, (max_items + 15) / 16));
+        v.reduceRB = std::max(1, std::min(64, (max_items + 31) / 32));
     }
 
     const size_t NT = (size_t)N * T, LT = (size_t)L * T;
@@ -290,7 +290,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     TRY(dev_alloc(c, &v.nu_prev, (size_t)S * T)); TRY(dev_alloc(c, &v.nu_valid, S)); TRY(dev_alloc(c, &v.sto_fail, S));
     TRY(dev_alloc(c, &v.item_fail, v.nStoItems));
     TRY(dev_alloc(c, &v.part2, (size_t)N * v.reduceRB * T)); TRY(dev_alloc(c, &v.part2_cost, v.reduceRB));
-    TRY(dev_alloc(c, &v.reduce_ticket, N));
+    TRY(dev_alloc(c, &v.reduce_ticket, (size_t)N * ((T + 31) / 32)));
     double *cons = nullptr;
     TRY(dev_alloc(c, &cons, NT + 2 * LT + 1));
     c->own_cons = cons;

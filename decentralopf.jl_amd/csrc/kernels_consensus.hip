@@ -214,69 +214,91 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
     __shared__ int last_sh;
     const int tid = threadIdx.x;
     const int N = v.N, L = v.L, T = v.T, RB = v.reduceRB;
-    if ((int)blockIdx.x < N * RB) {
-        const int n = blockIdx.x / RB, rb = blockIdx.x - n * RB;
-        const int TT = T < 256 ? T : 256, R = 256 / TT;
-        const int r = tid / TT, tt = tid - r * TT;
+    constexpr int TT = 32, R = 8;                       // block = 8 item lanes x 32 timesteps
+    const int TC = (T + TT - 1) / TT;
+    if ((int)blockIdx.x < N * RB * TC) {
+        const int tcx = blockIdx.x % TC, nrb = blockIdx.x / TC;
+        const int n = nrb / RB, rb = nrb - n * RB;
+        const int r = tid >> 5, tt = tid & 31, t = tcx * TT + tt;
         const int g0 = v.node_gitem_beg[n], ngi = v.node_gitem_beg[n + 1] - g0;
         const int s0 = v.node_sitem_beg[n], nsi = v.node_sitem_beg[n + 1] - s0;
         const int ni = ngi + nsi;                       // generator items first, then storage items
         const int per = (ni + RB - 1) / RB;
         const int i0 = rb * per, i1 = min(ni, i0 + per);
-        double *p2 = v.part2 + ((size_t)n * RB + rb) * T;
-        for (int tc = 0; tc < T; tc += TT) {
-            const int t = tc + tt;
-            double acc = 0.0;
-            if (r < R && t < T) {
-#pragma unroll 4
-                for (int i = i0 + r; i < i1; i += R)
-                    acc += i < ngi ? v.part_ginj[(size_t)(g0 + i) * T + t]
-                                   : v.part_sinj[(size_t)(s0 + i - ngi) * T + t] + v.part_sinj_w[(size_t)(s0 + i - ngi) * T + t];
+        double acc = 0.0;
+        if (t < T) {
+            // two independent chains keep several loads in flight; the grouping is fixed, so is the result
+            double a0 = 0.0, a1 = 0.0;
+            int i = i0 + r;
+            for (; i + R < i1; i += 2 * R) {
+                const int j = i + R;
+                a0 += i < ngi ? v.part_ginj[(size_t)(g0 + i) * T + t]
+                              : v.part_sinj[(size_t)(s0 + i - ngi) * T + t] + v.part_sinj_w[(size_t)(s0 + i - ngi) * T + t];
+                a1 += j < ngi ? v.part_ginj[(size_t)(g0 + j) * T + t]
+                              : v.part_sinj[(size_t)(s0 + j - ngi) * T + t] + v.part_sinj_w[(size_t)(s0 + j - ngi) * T + t];
             }
-            __syncthreads();
-            red[tid] = acc;
-            __syncthreads();
-            if (r == 0 && t < T) {
-                double sum = 0.0;
-                for (int q = 0; q < R; ++q) sum += red[q * TT + tt];
-                p2[t] = sum;
-            }
+            if (i < i1)
+                a0 += i < ngi ? v.part_ginj[(size_t)(g0 + i) * T + t]
+                              : v.part_sinj[(size_t)(s0 + i - ngi) * T + t] + v.part_sinj_w[(size_t)(s0 + i - ngi) * T + t];
+            acc = a0 + a1;
         }
-        // cost partials ride with the first node's slices
-        if (n == 0) {
+        red[tid] = acc;
+        __syncthreads();
+        if (r == 0 && t < T) {
+            double sum = 0.0;
+            for (int q = 0; q < R; ++q) sum += red[q * TT + tt];
+            v.part2[((size_t)n * RB + rb) * T + t] = sum;
+        }
+        // cost partials ride with the first node's slices of the first timestep chunk
+        if (n == 0 && tcx == 0) {
             const int nc = v.nGenItems + v.nStoItems, cper = (nc + RB - 1) / RB;
             const int c0 = rb * cper, c1 = min(nc, c0 + cper);
             double c = 0.0;
-            for (int i = c0 + tid; i < c1; i += 256) c += i < v.nGenItems ? v.part_gcost[i] : v.part_scost[i - v.nGenItems] + v.part_scost_w[i - v.nGenItems];
+            for (int i = c0 + tid; i < c1; i += 256)
+                c += i < v.nGenItems ? v.part_gcost[i] : v.part_scost[i - v.nGenItems] + v.part_scost_w[i - v.nGenItems];
             c = block_sum256(c, red);
             if (tid == 0) v.part2_cost[rb] = c;
         }
-        // publish, take a ticket; the last block of this node finishes the sum
-        // (agent-scope release by every storing thread, drained before the ticket; the last block
-        //  acquires before it reads the other blocks' slices — cdna_hip_programming.md G16)
-        __threadfence();
+        // publish, take a ticket; the last block of this (node, timestep chunk) finishes the sum.
+        // Hand-off per cdna_hip_programming.md G16: every storing wave drains its stores, the block meets,
+        // ONE lane releases at agent scope and takes the ticket; the last block's lane acquires, the block
+        // meets again, then everybody reads the other blocks' slices with plain loads.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) last_sh = (atomicAdd(&v.reduce_ticket[n], 1) == RB - 1);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int last = atomicAdd(&v.reduce_ticket[n * TC + tcx], 1) == RB - 1;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            last_sh = last;
+        }
         __syncthreads();
         if (last_sh) {
-            __threadfence();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            for (int t = tid; t < T; t += 256) {
-                double sum = 0.0;
-                for (int q = 0; q < RB; ++q) sum += v.part2[((size_t)n * RB + q) * T + t];
-                v.cons[n + (size_t)N * t] = sum;
+            // 8 lanes per timestep take interleaved slices; combined in a fixed order
+            double sum = 0.0;
+            if (t < T)
+                for (int q = r; q < RB; q += R) sum += v.part2[((size_t)n * RB + q) * T + t];
+            __syncthreads();
+            red[tid] = sum;
+            __syncthreads();
+            if (r == 0 && t < T) {
+                double tot = 0.0;
+                for (int q = 0; q < R; ++q) tot += red[q * TT + tt];
+                v.cons[n + (size_t)N * t] = tot;
             }
-            if (n == 0 && tid == 0) {
+            if (n == 0 && tcx == 0 && tid == 0) {
                 double c = 0.0;
                 for (int q = 0; q < RB; ++q) c += v.part2_cost[q];
                 v.cons[(size_t)N * T + 2 * (size_t)L * T] = c;
             }
-            if (tid == 0) v.reduce_ticket[n] = 0;       // ready for the next iteration
+            if (tid == 0) v.reduce_ticket[n * TC + tcx] = 0;       // ready for the next iteration
         }
     } else {
         const size_t LT = (size_t)L * T;
-        const size_t idx = (size_t)(blockIdx.x - N * RB) * 256 + tid;
+        const size_t idx = (size_t)(blockIdx.x - N * RB * TC) * 256 + tid;
         if (idx < 2 * LT) {
             const int which = idx >= LT;
             const size_t rem = idx - which * LT;            // l + L*t
@@ -292,7 +314,8 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
 void launch_reduce(const DevView &v, hipStream_t s)
 {
     const size_t LT2 = 2 * (size_t)v.L * v.T;
-    const int blocks = v.N * v.reduceRB + (int)((LT2 + 255) / 256);
+    const int TC = (v.T + 31) / 32;
+    const int blocks = v.N * v.reduceRB * TC + (int)((LT2 + 255) / 256);
     hipLaunchKernelGGL(k_reduce, dim3(blocks), dim3(256), 0, s, v);
 }
 
@@ -304,15 +327,14 @@ __device__ __forceinline__ void atomic_max_pos(unsigned long long *addr, double 
     atomicMax(addr, (unsigned long long)__double_as_longlong(vpos));   // vpos >= 0: bit order = value order
 }
 
+// element i of the dual step: injection / imbalance / flows from the consensus vector, then the
+// lambda (i < T) and mu, rho (i < L*T) ascent steps; returns this element's |dual change|
 template <bool UPDATE>
-__global__ __launch_bounds__(256) void k_dual(DevView v)
+__device__ __forceinline__ void dual_body(const DevView &v, size_t i, double &rl, double &rm, double &rr)
 {
-    if (UPDATE && v.st->halt) return;
     const int N = v.N, L = v.L, T = v.T;
     const size_t NT = (size_t)N * T, LT = (size_t)L * T;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const double *cinj = v.cons, *cU = v.cons + NT, *cK = cU + LT;
-    double rl = 0.0, rm = 0.0, rr = 0.0;
     if (i < NT) v.inj[i] = cinj[i] - v.demand[i];                         // results.jl:58-100
     if (i < (size_t)T) {
         const int t = (int)i;
@@ -323,7 +345,7 @@ __global__ __launch_bounds__(256) void k_dual(DevView v)
             const double lo = v.lam[t], ln = lo + v.gamma * sum;          // update_duals.jl:8-13
             v.lam_used[t] = lo;
             v.lam[t] = ln;
-            rl = fabs(ln - lo);
+            rl = fmax(rl, fabs(ln - lo));
         }
     }
     if (i < LT) {
@@ -340,10 +362,42 @@ __global__ __launch_bounds__(256) void k_dual(DevView v)
             const double rn = (ro + v.gamma * (aK - f - F)) * (aK <= v.mask_thr ? 1.0 : 0.0);   // :30-37
             v.mu_used[i] = mo; v.rho_used[i] = ro;
             v.mu[i] = mn; v.rho[i] = rn;
-            rm = fabs(mn - mo);
-            rr = fabs(rn - ro);
+            rm = fmax(rm, fabs(mn - mo));
+            rr = fmax(rr, fabs(rn - ro));
         }
     }
+}
+
+// price[n,t] = lambda_t + sum_l ptdf[l,n] (mu - rho)[l,t]   (subproblems.jl:67-74), element i = n + N*t
+__device__ __forceinline__ void price_body(const DevView &v, size_t i)
+{
+    const int N = v.N, L = v.L;
+    const int n = (int)(i % N), t = (int)(i / N);
+    double p = v.lam[t];
+    for (int l = 0; l < L; ++l) p += v.ptdf[l + (size_t)L * n] * (v.mu[l + (size_t)L * t] - v.rho[l + (size_t)L * t]);
+    v.price[i] = p;
+}
+
+// check_convergence!, convergence.jl:1-31 (one thread)
+__device__ __forceinline__ void status_update(const DevView &v, double r0, double r1, double r2)
+{
+    Status *st = v.st;
+    if (st->iteration != 1) {                                             // convergence.jl:3
+        st->res[0] = r0; st->res[1] = r1; st->res[2] = r2;
+        st->converged = (r0 < v.eps) && (r1 < v.eps) && (r2 < v.eps);
+    }
+    st->iters_total += 1;
+    if (!st->converged) st->iteration += 1;                               // convergence.jl:25-30
+    st->halt = st->converged || (v.max_iters > 0 && st->iteration > v.max_iters);
+}
+
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void k_dual(DevView v)
+{
+    if (UPDATE && v.st->halt) return;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    double rl = 0.0, rm = 0.0, rr = 0.0;
+    dual_body<UPDATE>(v, i, rl, rm, rr);
     if (UPDATE) {
         // wave max, then one atomic per wave (max is order independent: deterministic)
         for (int d = 32; d > 0; d >>= 1) {
@@ -356,44 +410,69 @@ __global__ __launch_bounds__(256) void k_dual(DevView v)
             if (rm > 0.0) atomic_max_pos(&v.st->resbits[1], rm);
             if (rr > 0.0) atomic_max_pos(&v.st->resbits[2], rr);
         }
-        if (i == 0) v.st->total_cost = v.cons[NT + 2 * LT];
+        if (i == 0) v.st->total_cost = v.cons[(size_t)v.N * v.T + 2 * (size_t)v.L * v.T];
     }
 }
 
 template <bool UPDATE>
 __global__ __launch_bounds__(256) void k_price(DevView v)
 {
-    const int N = v.N, L = v.L;
-    const size_t NT = (size_t)N * v.T;
+    const size_t NT = (size_t)v.N * v.T;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     // recomputed even after a halt: the duals are frozen then, so the values are identical
-    if (i < NT) {
-        const int n = (int)(i % N), t = (int)(i / N);
-        double p = v.lam[t];
-        for (int l = 0; l < L; ++l) p += v.ptdf[l + (size_t)L * n] * (v.mu[l + (size_t)L * t] - v.rho[l + (size_t)L * t]);
-        v.price[i] = p;
-    }
+    if (i < NT) price_body(v, i);
     if (UPDATE && i == 0) {
         Status *st = v.st;
         if (st->halt) return;
-        if (st->iteration != 1) {                                         // convergence.jl:3
-            double r0 = __longlong_as_double((long long)st->resbits[0]);
-            double r1 = __longlong_as_double((long long)st->resbits[1]);
-            double r2 = __longlong_as_double((long long)st->resbits[2]);
-            st->res[0] = r0; st->res[1] = r1; st->res[2] = r2;
-            st->converged = (r0 < v.eps) && (r1 < v.eps) && (r2 < v.eps);
-        }
+        const double r0 = __longlong_as_double((long long)st->resbits[0]);
+        const double r1 = __longlong_as_double((long long)st->resbits[1]);
+        const double r2 = __longlong_as_double((long long)st->resbits[2]);
         st->resbits[0] = st->resbits[1] = st->resbits[2] = 0ull;
-        st->iters_total += 1;
-        if (!st->converged) st->iteration += 1;                           // convergence.jl:25-30
-        st->halt = st->converged || (v.max_iters > 0 && st->iteration > v.max_iters);
+        status_update(v, r0, r1, r2);
     }
 }
+
+// dual step + prices + stop test in ONE block when the consensus state is small (every copper-plate case):
+// saves a launch per iteration, which is what the small configurations are bound by
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void k_dual_price_small(DevView v)
+{
+    if (UPDATE && v.st->halt) return;
+    __shared__ double red[3][256];
+    const int tid = threadIdx.x;
+    const size_t NT = (size_t)v.N * v.T, LT = (size_t)v.L * v.T;
+    const size_t n1 = NT > LT ? NT : LT;
+    double rl = 0.0, rm = 0.0, rr = 0.0;
+    for (size_t i = tid; i < n1; i += 256) dual_body<UPDATE>(v, i, rl, rm, rr);
+    if (UPDATE) {
+        red[0][tid] = rl; red[1][tid] = rm; red[2][tid] = rr;
+        if (tid == 0) v.st->total_cost = v.cons[NT + 2 * LT];
+    }
+    __syncthreads();                       // the block's own global writes (new duals) are visible after this
+    for (size_t i = tid; i < NT; i += 256) price_body(v, i);
+    if (UPDATE) {
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) {
+                red[0][tid] = fmax(red[0][tid], red[0][tid + s]);
+                red[1][tid] = fmax(red[1][tid], red[1][tid + s]);
+                red[2][tid] = fmax(red[2][tid], red[2][tid + s]);
+            }
+            __syncthreads();
+        }
+        if (tid == 0) status_update(v, red[0][0], red[1][0], red[2][0]);
+    }
+}
+
+constexpr size_t kSmallConsensus = 4096;
 
 void launch_dual(const DevView &v, hipStream_t s)
 {
     const size_t NT = (size_t)v.N * v.T, LT = (size_t)v.L * v.T;
     const size_t n1 = NT > LT ? NT : LT;
+    if (n1 <= kSmallConsensus) {
+        hipLaunchKernelGGL(k_dual_price_small<true>, dim3(1), dim3(256), 0, s, v);
+        return;
+    }
     hipLaunchKernelGGL(k_dual<true>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_price<true>, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, v);
 }
@@ -432,6 +511,10 @@ void launch_derive(const DevView &v, hipStream_t s, bool from_primal)
     if (from_primal) {        // serial over a node's agents: fine for tests / resume, not a hot path
         hipLaunchKernelGGL(k_derive_cons, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, v);
         if (v.S > 0) hipLaunchKernelGGL(k_derive_level, dim3((unsigned)((v.S + 255) / 256)), dim3(256), 0, s, v);
+    }
+    if (n1 <= kSmallConsensus) {
+        hipLaunchKernelGGL(k_dual_price_small<false>, dim3(1), dim3(256), 0, s, v);
+        return;
     }
     hipLaunchKernelGGL(k_dual<false>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_price<false>, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, v);
