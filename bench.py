@@ -192,16 +192,17 @@ def main():
             traffic = None       # HBM bytes per launch from the committed PMC passes (scripts/profile.sh)
             pmc_file = os.path.join(ROOT, "profiles", "r01_pmc.json")
             if os.path.exists(pmc_file):
-                rec = json.load(open(pmc_file)).get(args.workload, {}).get("k_gen_update")
+                recs = json.load(open(pmc_file)).get(args.workload, {})
+                rec = recs.get("k_gen_update_pair") if pp.L == 0 and pp.T % 2 == 0 else recs.get("k_gen_update")
                 if rec:        # gfx950: FETCH_SIZE counts half of a streaming read (MI355X_MICROARCH.md, HBM); unit KiB
                     traffic = (2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0
-            out["roofline"] = {"bound": "hbm", "kernel": "k_gen_update", "achieved": ach, "peak": peak,
+            out["roofline"] = {"bound": "hbm", "kernel": "k_gen_update_pair" if (pp.L == 0 and pp.T % 2 == 0) else "k_gen_update", "achieved": ach, "peak": peak,
                                "unit": "GB/s", "frac": ach / peak, "traffic": traffic,
                                "algorithmic_bytes_per_launch": gen_b + shared_b,
                                "kernel_ms": k_ms, "kernel_ms_with_event_overhead": timing["gen_ms"]}
             out["kernels_ms"] = {k: v for k, v in timing.items() if k != "iters"}
             s_ms = max(timing["sto_ms"] - timing["empty_ms"], 1e-6)
-            out["storage_kernel"] = {"kernel": "k_sto_update", "bound": "fp64 VALU (price-threshold recursion), not HBM",
+            out["storage_kernel"] = {"kernel": "k_sto_warm + k_sto_update", "bound": "fp64 VALU (segmented Newton + certificate; scan fallback), not HBM",
                                      "algorithmic_bytes_per_launch": sto_b, "kernel_ms": s_ms,
                                      "achieved_GBps": sto_b / s_ms * 1e-6}
             whole = (gen_b + sto_b + shared_b) / (dt / args.steps) / 1e9

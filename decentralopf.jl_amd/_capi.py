@@ -114,6 +114,7 @@ class CApi:
             self._sig("bind_consensus", C.c_int, [ctxp, C.c_void_p])
             self._sig("solver_failures", C.c_int64, [ctxp])
             self._sig("iterate_timed", C.c_int, [ctxp, C.c_int32, C.POINTER(DopfTiming)])
+            self._sig("debug_stats", C.c_int, [ctxp, C.POINTER(C.c_uint64)])
             self._sig("version", C.c_char_p, [])
             self._sig("default_params", None, [C.POINTER(DopfParams)])
         else:   # oracle-only entry points (tests)
@@ -234,6 +235,12 @@ class Engine:
         t = DopfTiming()
         self._chk(self.api.iterate_timed(self._ctx, int(n_iters), C.byref(t)))
         return {k: getattr(t, k) for k, _ in DopfTiming._fields_}
+
+    def warm_start_stats(self):
+        """(storages the warm-start kernel solved, storages it left to the scan kernel) in the LAST iteration."""
+        out = (C.c_uint64 * 9)()
+        self._chk(self.api.debug_stats(self._ctx, out))
+        return int(out[3]), int(out[4])
 
     def set_threads(self, n: int):
         self.api.set_threads(self._ctx, int(n))

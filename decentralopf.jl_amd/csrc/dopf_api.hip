@@ -226,6 +226,8 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     v.use_warm = (L == 0 && S > 0 && lc.stoNCH <= 3 && !(q->flags & DOPF_F_NO_WARM_START)) ? 1 : 0;
     v.genTT = std::min(T, 512);
     v.genR = 512 / v.genTT;
+    v.genTT2 = (L == 0 && T % 2 == 0 && T / 2 <= 512) ? T / 2 : 0;
+    v.genR2 = v.genTT2 ? 512 / v.genTT2 : 0;
 
     // sort agents by node (stable), remember the permutation
     c->gen_perm.resize(G);
@@ -244,7 +246,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     std::vector<Item> gitems, sitems;
     std::vector<int> ngb, nsb, ngib, nsib;
     {
-        const int R = v.genR;
+        const int R = v.genTT2 ? v.genR2 : v.genR;
         int chunk = std::max(R, (G + 2047) / 2048);
         chunk = (chunk + R - 1) / R * R;
         make_items(gnode, N, chunk, gitems, ngb, ngib);

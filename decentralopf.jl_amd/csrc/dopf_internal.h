@@ -44,6 +44,7 @@ struct DevView {
     int N, L, T, G, S, M2;          // M2 = 2L
     int nGenItems, nStoItems;
     int genTT, genR;                // generator block tiling: TT = min(T, 512) timesteps x R agents
+    int genTT2, genR2;              // pair kernel (copper plate, even T <= 1024): T/2 double2 columns x R2 agents; 0 = off
     int reduceRB;                   // reduce blocks per node (two-level fixed-order sum)
     int use_warm;                   // storage warm-start kernel runs first; the scan kernel serves its failures
     int max_iters;

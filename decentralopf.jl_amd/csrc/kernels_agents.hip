@@ -107,10 +107,61 @@ __global__ __launch_bounds__(512) void k_gen_update(DevView v)
     if (tid == 0) v.part_gcost[blockIdx.x] = red[0];
 }
 
+// Copper plate, even T: each thread owns TWO consecutive timesteps of an agent, so every P access is a
+// 16-byte-per-lane double2 (the widest coalesced form), half as many load/store instructions per byte.
+__global__ __launch_bounds__(512) void k_gen_update_pair(DevView v)
+{
+    if (v.st->halt) return;
+    __shared__ double red[2][512];
+    const Item it = v.gen_items[blockIdx.x];
+    const int T = v.T, N = v.N, TT = v.genTT2, R = v.genR2;     // TT = T/2 pair columns
+    const int tid = threadIdx.x;
+    const int r = tid / TT, tt = tid - r * TT;
+    const double w = v.w_prox, gam = v.gamma;
+    const double inv = 1.0 / (w + gam);
+    double cost = 0.0, acc0 = 0.0, acc1 = 0.0;
+    if (r < R) {
+        const int t = 2 * tt;
+        const double sh0 = (v.price[it.node + N * t] + gam * v.s[t]) * inv;
+        const double sh1 = (v.price[it.node + N * (t + 1)] + gam * v.s[t + 1]) * inv;
+        double2 *P2 = reinterpret_cast<double2 *>(v.P);
+        const size_t half = (size_t)(T >> 1);
+#pragma unroll 4
+        for (int g = it.a0 + r; g < it.a1; g += R) {
+            const size_t e = (size_t)g * half + tt;
+            const double mc = v.gen_mc[g], pm = v.gen_pmax[g];
+            const double2 p0 = P2[e];
+            double2 pn;
+            pn.x = clampd(p0.x - (mc * inv + sh0), 0.0, pm);
+            pn.y = clampd(p0.y - (mc * inv + sh1), 0.0, pm);
+            P2[e] = pn;
+            acc0 += pn.x; acc1 += pn.y;
+            cost += mc * (pn.x + pn.y);
+        }
+    }
+    red[0][tid] = acc0; red[1][tid] = acc1;
+    __syncthreads();
+    if (r == 0 && tt < TT) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int q = 0; q < R; ++q) { s0 += red[0][q * TT + tt]; s1 += red[1][q * TT + tt]; }
+        v.part_ginj[(size_t)blockIdx.x * T + 2 * tt] = s0;
+        v.part_ginj[(size_t)blockIdx.x * T + 2 * tt + 1] = s1;
+    }
+    __syncthreads();
+    red[0][tid] = cost;
+    __syncthreads();
+    for (int sft = 256; sft > 0; sft >>= 1) {
+        if (tid < sft) red[0][tid] += red[0][tid + sft];
+        __syncthreads();
+    }
+    if (tid == 0) v.part_gcost[blockIdx.x] = red[0][0];
+}
+
 void launch_gen_update(const DevView &v, hipStream_t s)
 {
     if (v.nGenItems == 0) return;
     if (v.L > 0) hipLaunchKernelGGL(k_gen_update<true>, dim3(v.nGenItems), dim3(512), 0, s, v);
+    else if (v.genTT2 > 0) hipLaunchKernelGGL(k_gen_update_pair, dim3(v.nGenItems), dim3(512), 0, s, v);
     else hipLaunchKernelGGL(k_gen_update<false>, dim3(v.nGenItems), dim3(512), 0, s, v);
 }
 
@@ -883,7 +934,12 @@ __global__ __launch_bounds__(256) void k_sto_warm(DevView v)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) red[(grp * LPS + li) * NCH + c] = accQ[c];
     redc[tid] = accCost;
-    const int blockFail = __syncthreads_count(anyFail);      // storages of this item left to the scan kernel
+    __shared__ int failCount;
+    if (tid == 0) failCount = 0;
+    __syncthreads();
+    if (anyFail) atomicAdd(&failCount, anyFail);     // integer: order does not matter
+    __syncthreads();
+    const int blockFail = failCount;                 // storages of this item left to the scan kernel
     if (grp == 0) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {

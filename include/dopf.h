@@ -162,6 +162,10 @@ typedef struct dopf_timing {
 int dopf_iterate_timed(dopf_ctx *ctx, int32_t n_iters, dopf_timing *out);
 
 int64_t dopf_solver_failures(dopf_ctx *ctx);
+/* Diagnostics, 9 counters: [0..2] scan-kernel statistics (only in -DDOPF_STATS builds), [3] storages the
+ * warm-start kernel solved in the LAST iteration, [4] storages it left to the scan kernel, [5..8] reasons
+ * (DOPF_STATS builds). */
+int dopf_debug_stats(dopf_ctx *ctx, uint64_t *out9);
 /* Diagnostics (L > 0): the breakpoint table of node n, timestep t that the last x-update used:
  * beta, psi: 2L doubles (first *m valid, ascending), slope: 2L+1, psi0 = Psi(0). */
 int dopf_debug_table(dopf_ctx *ctx, int32_t n, int32_t t, double *beta, double *psi, double *slope,

@@ -101,6 +101,37 @@ def test_hip_free_running_trajectory(hip_api, oracle_api):
     assert max_diff(state_of(h), state_of(o), keys=["P", "D", "C", "E", "lam", "inj"])[0] < 1e-8
 
 
+def test_hip_warm_start_is_exact_and_used(hip_api, oracle_api):
+    """The warm-start storage kernel (previous contact structure + KKT certificate) against the cold scan
+    kernel and the oracle over a free run; and it must really carry the load in steady state."""
+    pp = synth.synthetic_case(400, 120, 24, seed=41)
+    g = 1.0 / (pp.G + pp.S)
+    warm = make_engine(hip_api, pp, eps=0.0, gamma=g)
+    cold = make_engine(hip_api, pp, eps=0.0, gamma=g, flags=_capi.F_NO_WARM_START)
+    ora = make_engine(oracle_api, pp, mode=1, eps=0.0, gamma=g)
+    for n in (1, 1, 8, 40, 100):
+        warm.iterate(n)
+        cold.iterate(n)
+        ora.iterate(n)
+        a, b, c = state_of(warm), state_of(cold), state_of(ora)
+        assert max_diff(a, b, keys=["P", "D", "C", "E", "lam", "inj"])[0] < 1e-8
+        assert max_diff(a, c, keys=["P", "D", "C", "E", "lam", "inj"])[0] < 1e-8
+    solved, left = warm.warm_start_stats()
+    assert solved + left == pp.S and solved >= 0.5 * pp.S, (solved, left)
+    assert cold.warm_start_stats() == (0, pp.S)
+    assert warm.solver_failures() == 0 and cold.solver_failures() == 0
+    # T = 96 (32 lanes x 3) and T = 168 (64 x 3) variants of the same kernel
+    for T, seed in ((96, 42), (168, 43)):
+        pp = synth.synthetic_case(100, 40, T, seed=seed)
+        g = 1.0 / (pp.G + pp.S)
+        warm = make_engine(hip_api, pp, eps=0.0, gamma=g)
+        ora = make_engine(oracle_api, pp, mode=1, eps=0.0, gamma=g)
+        warm.iterate(60)
+        ora.iterate(60)
+        assert max_diff(state_of(warm), state_of(ora), keys=["P", "D", "C", "E", "lam", "inj"])[0] < 1e-8
+        assert warm.warm_start_stats()[0] >= 0.5 * pp.S
+
+
 def test_hip_edge_cases(hip_api, oracle_api):
     pp = synth.synthetic_case(8, 4, 6, seed=10)
     pp.sto_pmax[0] = 0.0          # cannot move
