@@ -22,6 +22,7 @@ using namespace dopf;
 namespace {
 
 constexpr int kUnroll = 16;
+constexpr int kCheckEvery = 512;
 thread_local char g_create_err[512];
 
 }  // namespace
@@ -332,23 +333,32 @@ int dopf_iterate(dopf_ctx *c, int32_t n_iters, int32_t *iters_done, int32_t *con
     if (!c || n_iters < 0) return fail(c, DOPF_E_INVALID, "bad argument");
     DeviceGuard guard(c->device);
     const int before = c->host_st.iters_total;
-    if (c->q.flags & DOPF_F_NO_GRAPH) {
-        for (int i = 0; i < n_iters; ++i) { enqueue_local(c); enqueue_apply(c); }
-    } else {
-        if (!c->graphs_valid) {
-            int rc = build_graph(c, 1, &c->graph1);
-            if (rc) return rc;
-            rc = build_graph(c, kUnroll, &c->graphU);
-            if (rc) return rc;
-            c->graphs_valid = true;
-        }
-        int left = n_iters;
-        for (; left >= kUnroll; left -= kUnroll) HIPCHK(c, hipGraphLaunch(c->graphU, c->main));
-        for (; left > 0; --left) HIPCHK(c, hipGraphLaunch(c->graph1, c->main));
+    const bool eager = (c->q.flags & DOPF_F_NO_GRAPH) != 0;
+    if (!eager && !c->graphs_valid) {
+        int rc = build_graph(c, 1, &c->graph1);
+        if (rc) return rc;
+        rc = build_graph(c, kUnroll, &c->graphU);
+        if (rc) return rc;
+        c->graphs_valid = true;
     }
-    HIPCHK(c, hipGetLastError());
-    int rc = read_status(c);
-    if (rc) return rc;
+    // Enqueue in slices and look at the device status word between slices, so that a converged (or capped)
+    // run stops being fed no-op launches; one sync per kCheckEvery iterations costs nothing measurable.
+    int left = n_iters;
+    while (left > 0) {
+        int slice = std::min(left, kCheckEvery);
+        left -= slice;
+        if (eager) {
+            for (int i = 0; i < slice; ++i) { enqueue_local(c); enqueue_apply(c); }
+        } else {
+            for (; slice >= kUnroll; slice -= kUnroll) HIPCHK(c, hipGraphLaunch(c->graphU, c->main));
+            for (; slice > 0; --slice) HIPCHK(c, hipGraphLaunch(c->graph1, c->main));
+        }
+        HIPCHK(c, hipGetLastError());
+        const int rc = read_status(c);
+        if (rc) return rc;
+        if (c->host_st.halt) break;
+    }
+    if (n_iters == 0) { const int rc = read_status(c); if (rc) return rc; }
     if (iters_done) *iters_done = c->host_st.iters_total - before;
     if (converged) *converged = c->host_st.converged;
     return DOPF_OK;

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Central-LP optima (SciPy/HiGHS, tests/central_lp.py = src/opf_central_reference.jl:21-53 restated) of the
+seed-stable synthetic BASELINE configurations, so that the GPU tests can check "converged objective within
+1e-3 of the central optimum" without solving a 4.8-million-variable LP on the GPU box (config2: ~45 s here)."""
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+import dopf_pkg  # noqa: E402
+
+dopf_pkg.load()
+from decentralopf_jl_amd import synth  # noqa: E402
+from central_lp import solve_central  # noqa: E402
+
+out = {"source": "scipy.optimize.linprog(method='highs') on synth.baseline_config(i); objective = sum mc*P + sum mc*(D+C)"}
+for idx in (1, 2):
+    pp = synth.baseline_config(idx)
+    t0 = time.time()
+    r = solve_central(pp)
+    out[f"config{idx}"] = {"G": pp.G, "S": pp.S, "T": pp.T, "objective": r["objective"], "seed": synth.SEED}
+    print(idx, r["objective"], f"{time.time() - t0:.1f}s")
+json.dump(out, open(os.path.join(HERE, "synthetic_optima.json"), "w"), indent=1)

@@ -243,6 +243,20 @@ def test_hip_full_size_properties(hip_api, name, idx, scale):
     assert e.solver_failures() == 0
 
 
+def test_hip_config2_time_to_residual_and_optimum(hip_api):
+    """BASELINE config 2 (50k agents x 96): gamma = 1/A reaches the 1e-3 residual in a few hundred iterations
+    and the cost sits within 1e-3 (in fact ~1e-5) of the central LP optimum (tests/golden/synthetic_optima.json)."""
+    from conftest import load_golden
+    pp = synth.baseline_config(2)
+    opt = load_golden("synthetic_optima")["config2"]
+    assert (opt["G"], opt["S"], opt["T"]) == (pp.G, pp.S, pp.T)
+    e = make_engine(hip_api, pp, gamma=1.0 / (pp.G + pp.S), max_iters=20000)
+    done, conv = e.iterate(20000)
+    assert conv and done < 2000
+    assert abs(e.get_consensus()[4] - opt["objective"]) / opt["objective"] < 1e-3
+    assert e.solver_failures() == 0
+
+
 def test_hip_config1_reaches_central_optimum(hip_api):
     """BASELINE config 1 (1000 gens + 100 storages x 24): converges (gamma = 1/A) to the LP optimum."""
     pp = synth.baseline_config(1)
