@@ -72,15 +72,11 @@ def synthetic_case(n_gen: int, n_sto: int, T: int, *, N: int = 1, L: int = 0, se
         ptdf = _ptdf_from_edges(N, frm, to, sus, slack=0)
         # merit-order copper-plate dispatch -> flows -> capacities
         order = np.argsort(gen_mc, kind="stable")
+        pm_sorted = gen_pmax[order]
+        before = np.cumsum(pm_sorted) - pm_sorted                     # capacity cheaper than each generator
+        take = np.clip(d_tot[None, :] - before[:, None], 0.0, pm_sorted[:, None])       # (G, T)
         inj = -demand.copy()
-        for k in range(T):
-            need = d_tot[k]
-            for g in order:
-                take = min(gen_pmax[g], need)
-                inj[gen_node[g], k] += take
-                need -= take
-                if need <= 0:
-                    break
+        np.add.at(inj, gen_node[order], take)
         flow = ptdf @ inj
         f_max = np.maximum(fmax_min, np.ceil(fmax_factor * np.abs(flow).max(axis=1)))
     else:
