@@ -292,6 +292,77 @@ __device__ __forceinline__ void box2(double a, double b, double ia, double idet,
     sg = (fD && fC) ? s2 : ((fD || fC) ? ia : 0.0);
 }
 
+// breakpoint table of Psi_{n,t} as one lane-timestep sees it
+struct TabRef {
+    const double *beta, *psi, *slope;
+    int m;
+    double psi0;
+};
+
+__device__ __forceinline__ TabRef tab_ref(const DevView &v, int node, int t)
+{
+    const size_t at = (size_t)node + (size_t)v.N * t;
+    TabRef r;
+    r.beta = v.tb_beta + at * v.M2;
+    r.psi = v.tb_psi + at * v.M2;
+    r.slope = v.tb_slope + at * (v.M2 + 1);
+    r.m = v.tb_m[at];
+    r.psi0 = v.tb_psi0[at];
+    return r;
+}
+
+// Psi_{n,t}(dl) from the table (first kink >= dl, then the piece left of it)
+__device__ __forceinline__ double tab_psi_at(const TabRef &tb, double dl)
+{
+    if (tb.m == 0) return tb.psi0 + tb.slope[0] * dl;
+    int lo = 0, hi = tb.m;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (tb.beta[mid] >= dl) hi = mid; else lo = mid + 1;
+    }
+    const int a = lo < tb.m ? lo : tb.m - 1;
+    return tb.psi[a] + tb.slope[lo] * (dl - tb.beta[a]);
+}
+
+// (D, C)(nu) of one storage timestep with lines: find the piece of Psi the solution lies on — first kink
+// whose residual r(beta) = beta - (D(z) - C(z) - q0), z = Psi(beta) + nu, is >= 0 (r is increasing) — then
+// the 2x2 box QP with that piece's slope. `hint` remembers the piece between calls: successive prices are
+// close, so two probes around the hint usually replace the 9 dependent table reads of a full bisection.
+__device__ __forceinline__ void eval_lines(const TabRef &tb, int &hint, double w, double iw, double mc, double pm,
+                                           double D0, double C0, double nu, double &dd, double &cc, double &s1,
+                                           double &psi_cur)
+{
+    const double q0 = D0 - C0;
+    double ab = 0.0, ap = tb.psi0, kap = tb.slope[0];
+    const int m = tb.m;
+    if (m > 0) {
+        auto rneg = [&](int idx) -> bool {
+            const double z = tb.psi[idx] + nu;
+            const double Dz = clampd(D0 - (mc + z) * iw, 0.0, pm), Cz = clampd(C0 - (mc - z) * iw, 0.0, pm);
+            return tb.beta[idx] - (Dz - Cz - q0) < 0.0;
+        };
+        int l2 = hint < 0 ? 0 : (hint > m ? m : hint);
+        const bool okLo = l2 == 0 || rneg(l2 - 1);
+        const bool okHi = l2 == m || !rneg(l2);
+        if (!(okLo && okHi)) {
+            int lo = okLo ? l2 + 1 : 0, hi = okLo ? m : l2 - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (!rneg(mid)) hi = mid; else lo = mid + 1;
+            }
+            l2 = lo;
+        }
+        hint = l2;
+        const int a = l2 < m ? l2 : m - 1;
+        ab = tb.beta[a]; ap = tb.psi[a]; kap = tb.slope[l2];
+    }
+    const double theta = ap - kap * (ab + q0);
+    const double a = w + kap;
+    box2(a, kap, 1.0 / a, 1.0 / (a * a - kap * kap), 2.0 / (a + kap), w * D0 - mc - theta - nu, w * C0 - mc + theta + nu,
+         pm, dd, cc, s1);
+    psi_cur = theta + kap * (dd - cc);       // Psi at the step's current net injection
+}
+
 struct StoAgent {
     double mc, pm, em;
 };
@@ -307,7 +378,7 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
     const int gbase = lane & ~(LPS - 1);
     const Item it = v.sto_items[blockIdx.x];
     const int T = v.T, N = v.N;
-    if (!LINES && v.use_warm && v.item_fail[blockIdx.x] == 0) {      // the warm-start kernel solved this whole item
+    if (v.use_warm && v.item_fail[blockIdx.x] == 0) {      // the warm-start kernel solved this whole item
         for (int t = tid; t < T; t += 256) v.part_sinj[(size_t)blockIdx.x * T + t] = 0.0;
         if (tid == 0) v.part_scost[blockIdx.x] = 0.0;
         return;
@@ -332,7 +403,7 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
 
     for (int rep = 0; rep < nRep; ++rep) {
         const int s = it.a0 + rep * NG + grp;
-        const bool live = s < it.a1 && (LINES || !v.use_warm || v.sto_fail[s] != 0);
+        const bool live = s < it.a1 && (!v.use_warm || v.sto_fail[s] != 0);
         StoAgent ag;
         ag.mc = live ? v.sto_mc[s] : 0.0;
         ag.pm = live ? v.sto_pmax[s] : 0.0;
@@ -351,35 +422,19 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
         const double tol = 1e-11 * (1.0 + ag.em);
 
         // x_t(nu): net charge of timestep (li, c) at price nu
-        auto eval = [&](int c, double nu, double &dd, double &cc, double &s1) {
-            const int t = tbase + c;
-            const double q0 = D0[c] - C0[c];
+        int hint[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) hint[c] = 0;
+        const double iw = 1.0 / w;
+        auto eval = [&](int c, double nu, double &dd, double &cc, double &s1, double &pc) {
             if (!LINES) {
-                const double theta = th0[c] - gam * q0;
+                const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
                 box2(a0, gam, ia0, idet0, s20, w * D0[c] - ag.mc - theta - nu, w * C0[c] - ag.mc + theta + nu,
                      ag.pm, dd, cc, s1);
+                pc = theta + gam * (dd - cc);
             } else {
-                const size_t at = (size_t)it.node + (size_t)N * t;
-                const int m = v.tb_m[at];
-                const double *beta = v.tb_beta + at * v.M2, *psi = v.tb_psi + at * v.M2;
-                const double *slope = v.tb_slope + at * (v.M2 + 1);
-                double ab = 0.0, ap = v.tb_psi0[at], kap = slope[0];
-                if (m > 0) {
-                    int l2 = 0, h2 = m;       // first kink where dlt - (D(z) - C(z) - q0) >= 0
-                    while (l2 < h2) {
-                        const int mid = (l2 + h2) >> 1;
-                        const double z = psi[mid] + nu;
-                        const double Dz = clampd(D0[c] - (ag.mc + z) / w, 0.0, ag.pm);
-                        const double Cz = clampd(C0[c] - (ag.mc - z) / w, 0.0, ag.pm);
-                        if (beta[mid] - (Dz - Cz - q0) >= 0.0) h2 = mid; else l2 = mid + 1;
-                    }
-                    const int a = l2 < m ? l2 : m - 1;
-                    ab = beta[a]; ap = psi[a]; kap = slope[l2];
-                }
-                const double theta = ap - kap * (ab + q0);
-                const double a = w + kap;
-                box2(a, kap, 1.0 / a, 1.0 / (a * a - kap * kap), 2.0 / (a + kap), w * D0[c] - ag.mc - theta - nu,
-                     w * C0[c] - ag.mc + theta + nu, ag.pm, dd, cc, s1);
+                const TabRef tb = tab_ref(v, it.node, tbase + c);
+                eval_lines(tb, hint[c], w, iw, ag.mc, ag.pm, D0[c], C0[c], nu, dd, cc, s1, pc);
             }
         };
 
@@ -397,16 +452,17 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
             if (lane == 0) ++st_loops;
 #endif
             // -- one scan at price nu
-            double x[NCH], sg[NCH], Sv[NCH];
+            double x[NCH], sg[NCH], Sv[NCH], psc[NCH];
             Map3 loc;
             loc.A = 0.0; loc.LO = -INFINITY; loc.HI = INFINITY;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int t = tbase + c;
-                double dd = 0.0, cc = 0.0, s1 = 0.0;
-                if (t <= k && t < T) eval(c, nu, dd, cc, s1);
+                double dd = 0.0, cc = 0.0, s1 = 0.0, pc = 0.0;
+                if (t <= k && t < T) eval(c, nu, dd, cc, s1, pc);
                 x[c] = cc - dd;
                 sg[c] = s1;
+                psc[c] = pc;
                 loc.A += x[c];
                 loc.LO = clampd(loc.LO + x[c], 0.0, ag.em);
                 loc.HI = clampd(loc.HI + x[c], 0.0, ag.em);
@@ -453,23 +509,18 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
             // S_idx is flat at nu: jump just past the nearest kink of the x_t in its run (jlast, idx] in direction dir.
             // Any trial point is legitimate (the bracket keeps the search safe); this one has the right scale.
             auto flat_jump = [&](int idx, double dir) -> double {
-                double best = INFINITY;                   // distance to the nearest kink ahead
-                if (!LINES) {
-                    const double det0 = a0 * a0 - gam * gam, iamb = 1.0 / (a0 - gam);
+                // every step of a flat run has D and C on bounds, so its net injection (hence Psi) does not
+                // move with nu and the four prices at which D or C would leave a bound are closed form
+                double best = INFINITY;                   // distance to the nearest such price ahead
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) {
-                        if (tbase + c > idx || tbase + c <= jlast) continue;
-                        const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
-                        const double rD0 = w * D0[c] - ag.mc - theta, rC0 = w * C0[c] - ag.mc + theta;
-                        const double bp = gam * ag.pm, ap = a0 * ag.pm;
-                        const double fD = (a0 * rD0 + gam * rC0) * iamb, fC = -(a0 * rC0 + gam * rD0) * iamb, dp = det0 * ag.pm * iamb;
-                        const double cand[12] = {rD0 - ap, rD0, -rC0, ap - rC0, rD0 + bp - ap, rD0 + bp, -rC0 - bp,
-                                                 ap - rC0 - bp, fD, fD - dp, fC, fC + dp};
+                for (int c = 0; c < NCH; ++c) {
+                    if (tbase + c > idx || tbase + c <= jlast) continue;
+                    const double bD = w * D0[c] - ag.mc - psc[c], bC = ag.mc - w * C0[c] - psc[c], wp = w * ag.pm;
+                    const double cand[4] = {bD, bD - wp, bC, bC + wp};
 #pragma unroll
-                        for (int q = 0; q < 12; ++q) {
-                            const double d = (cand[q] - nu) * dir;
-                            if (d > 0.0) best = fmin(best, d);
-                        }
+                    for (int q = 0; q < 4; ++q) {
+                        const double d = (cand[q] - nu) * dir;
+                        if (d > 0.0) best = fmin(best, d);
                     }
                 }
                 best = group_min<LPS>(best);
@@ -561,10 +612,11 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
         for (int c = 0; c < NCH; ++c) {
             double s1;
             Dn[c] = 0.0; Cn[c] = 0.0;
-            if (live && tbase + c < T) eval(c, nuf[c], Dn[c], Cn[c], s1);
+            double pcx;
+            if (live && tbase + c < T) eval(c, nuf[c], Dn[c], Cn[c], s1, pcx);
             run += Cn[c] - Dn[c];
         }
-        if (!LINES && live && li == 0) v.nu_valid[s] = 1;
+        if (live && li == 0) v.nu_valid[s] = 1;
         const double incl = scan_sum<LPS>(run, lane);
         const double incl_prev = prev_lane<LPS>(incl);     // DPP: every lane must execute it (no ?: around it)
         double ev = li == 0 ? 0.0 : incl_prev;
@@ -577,7 +629,7 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
                 v.C[e] = Cn[c];
                 v.E[e] = ev;
                 if (LINES) v.dltS[e] = (Dn[c] - Cn[c]) - (D0[c] - C0[c]);
-                else v.nu_prev[e] = nuf[c];
+                v.nu_prev[e] = nuf[c];
                 accQ[c] += Dn[c] - Cn[c];
                 accCost += ag.mc * (Dn[c] + Cn[c]);
             }
@@ -695,7 +747,7 @@ __device__ __forceinline__ double next_lane(double x)
     return dppd<0x130, 0xF>(x, x);                     // wave_shl:1
 }
 
-template <int LPS, int NCH>
+template <int LPS, int NCH, bool LINES>
 __global__ __launch_bounds__(256) void k_sto_warm(DevView v)
 {
     if (v.st->halt) return;
@@ -720,7 +772,7 @@ __global__ __launch_bounds__(256) void k_sto_warm(DevView v)
     for (int c = 0; c < NCH; ++c) {
         const int t = tbase + c;
         accQ[c] = 0.0;
-        th0[c] = t < T ? v.price[it.node + N * t] + gam * v.s[t] : 0.0;
+        th0[c] = (!LINES && t < T) ? v.price[it.node + N * t] + gam * v.s[t] : 0.0;
     }
     const int nRep = (it.a1 - it.a0 + NG - 1) / NG;
     for (int rep = 0; rep < nRep; ++rep) {
@@ -729,6 +781,8 @@ __global__ __launch_bounds__(256) void k_sto_warm(DevView v)
         const double mc = live ? v.sto_mc[s] : 0.0, pm = live ? v.sto_pmax[s] : 0.0, em = live ? v.sto_emax[s] : 0.0;
         bool good = live && v.nu_valid[s] != 0;
         double D0[NCH], C0[NCH], nuv[NCH];
+        int hint[NCH];
+        const double iw = 1.0 / w;
         double run = 0.0;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -738,6 +792,7 @@ __global__ __launch_bounds__(256) void k_sto_warm(DevView v)
             D0[c] = ok ? v.D[e] : 0.0;
             C0[c] = ok ? v.C[e] : 0.0;
             nuv[c] = ok ? v.nu_prev[e] : 0.0;
+            hint[c] = 0;
             run += C0[c] - D0[c];
         }
         // previous level trajectory -> contacts -> segment ends
@@ -799,8 +854,14 @@ __global__ __launch_bounds__(256) void k_sto_warm(DevView v)
                 const int t = tbase + c;
                 double dd = 0.0, cc = 0.0, s1 = 0.0;
                 if (t < T) {
-                    const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
-                    box2(a0, gam, ia0, idet0, s20, w * D0[c] - mc - theta - nuv[c], w * C0[c] - mc + theta + nuv[c], pm, dd, cc, s1);
+                    if (!LINES) {
+                        const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
+                        box2(a0, gam, ia0, idet0, s20, w * D0[c] - mc - theta - nuv[c], w * C0[c] - mc + theta + nuv[c], pm, dd, cc, s1);
+                    } else {
+                        const TabRef tb = tab_ref(v, it.node, t);
+                        double pcx;
+                        eval_lines(tb, hint[c], w, iw, mc, pm, D0[c], C0[c], nuv[c], dd, cc, s1, pcx);
+                    }
                 }
                 Dv[c] = dd; Cv[c] = cc; sg[c] = s1;
                 if (st[c]) { rx = 0.0; rs = 0.0; f = 1; }
@@ -875,7 +936,9 @@ __global__ __launch_bounds__(256) void k_sto_warm(DevView v)
                 if (isend[c]) {
                     mlo[c] = mhi[c] = kind[c] != 0 ? nuv[c] : 0.0;
                     if (kind[c] != 0 && st[c] && base[t] == tgt[c]) {
-                        const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
+                        // with D = C = 0 the step's net injection is unchanged at q = 0: dlt = -q0
+                        const double q0 = D0[c] - C0[c];
+                        const double theta = LINES ? tab_psi_at(tab_ref(v, it.node, t), -q0) : th0[c] - gam * q0;
                         const double rD0 = w * D0[c] - mc - theta, rC0 = w * C0[c] - mc + theta;
                         if (rD0 <= -rC0 && nuv[c] >= rD0 - 1e-9 && nuv[c] <= -rC0 + 1e-9) { mlo[c] = rD0; mhi[c] = -rC0; }
                     }
@@ -921,6 +984,7 @@ __global__ __launch_bounds__(256) void k_sto_warm(DevView v)
                     v.C[e] = Cv[c];
                     v.E[e] = Ev[c];
                     v.nu_prev[e] = nuv[c];
+                    if (LINES) v.dltS[e] = (Dv[c] - Cv[c]) - (D0[c] - C0[c]);
                     accQ[c] += Dv[c] - Cv[c];
                     accCost += mc * (Dv[c] + Cv[c]);
                 }
@@ -973,7 +1037,10 @@ bool sto_config_supported(int T, Launch *lc)
 template <int LPS, int NCH>
 static void launch_sto_t(const DevView &v, hipStream_t s)
 {
-    if (v.use_warm) hipLaunchKernelGGL((k_sto_warm<LPS, (NCH <= 3 ? NCH : 3)>), dim3(v.nStoItems), dim3(256), 0, s, v);
+    if (v.use_warm) {
+        if (v.L > 0) hipLaunchKernelGGL((k_sto_warm<LPS, (NCH <= 3 ? NCH : 3), true>), dim3(v.nStoItems), dim3(256), 0, s, v);
+        else hipLaunchKernelGGL((k_sto_warm<LPS, (NCH <= 3 ? NCH : 3), false>), dim3(v.nStoItems), dim3(256), 0, s, v);
+    }
     if (v.L > 0) hipLaunchKernelGGL((k_sto_update<LPS, NCH, true>), dim3(v.nStoItems), dim3(256), 0, s, v);
     else hipLaunchKernelGGL((k_sto_update<LPS, NCH, false>), dim3(v.nStoItems), dim3(256), 0, s, v);
 }
