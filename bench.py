@@ -80,7 +80,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-iters", type=int, default=32)
     ap.add_argument("--overlap", action="store_true", help="fork the storage kernel onto a side stream")
+    ap.add_argument("--force-sharded", action="store_true", help="debug: drive the sharded (all-reduce) path even on one rank")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line (the JSON record): libraries that chat on stdout (RCCL prints a
+    # version banner at communicator creation) are sent to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -99,8 +106,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     idx, desc = WORKLOADS[args.workload]
@@ -120,7 +130,7 @@ def main():
     A_global = A_local * world
     gamma = args.gamma if args.gamma is not None else 1.0 / A_global
 
-    if world == 1:
+    if not sharded:
         eng = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, eps=0.0, device=local_rank,
                                                                         flags=_capi.F_OVERLAP_AGENTS if args.overlap else 0),
                            **pp.engine_kwargs())
@@ -164,7 +174,7 @@ def main():
     fails = eng.solver_failures()
 
     # per-kernel durations, live, HIP events on the streams the kernels run on (eager launches)
-    timing = eng.iterate_timed(args.timed_iters) if world == 1 else None
+    timing = eng.iterate_timed(args.timed_iters) if not sharded else None
 
     if rank == 0:
         gen_b, sto_b, shared_b = algorithmic_bytes(pp.G, pp.S, pp.T, pp.N, pp.L)
@@ -208,7 +218,7 @@ def main():
             whole = (gen_b + sto_b + shared_b) / (dt / args.steps) / 1e9
             out["whole_iteration_GBps"] = whole
             out["whole_iteration_frac_of_peak"] = whole / peak
-        if world == 1:
+        if not sharded:
             # the other half of BASELINE's metric: wall time until every |dual change| < 1e-3, from the zero state
             budget = int(max(64, min(100000, 10.0 * args.steps / dt)))     # at most ~10 s of iterations
             e2 = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, eps=1e-3, max_iters=budget, device=local_rank),
@@ -220,9 +230,9 @@ def main():
             out["time_to_1e-3_residual"] = {"seconds": t2 if conv2 else None, "iterations": done2, "converged": bool(conv2),
                                             "iteration_cap": budget, "total_cost": e2.get_consensus()[4]}
             e2.close()
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pp, gamma)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -266,3 +266,54 @@ def test_hip_config1_reaches_central_optimum(hip_api):
     assert conv and done < 2000
     opt = solve_central(pp)["objective"]
     assert abs(e.get_consensus()[4] - opt) / opt < 1e-3
+
+
+def _random_storage_case(rng, T):
+    """Copper-plate case with adversarial storage parameters and a random feasible previous iterate."""
+    G, S = int(rng.integers(3, 12)), int(rng.integers(4, 24))
+    pp = synth.synthetic_case(G, S, T, seed=int(rng.integers(1, 10**6)))
+    kind = rng.integers(0, 5, size=S)
+    pp.sto_mc[:] = np.where(kind == 0, 0.0, rng.integers(0, 40, size=S))          # no dead band / wide dead band
+    pp.sto_pmax[:] = rng.integers(1, 60, size=S).astype(float)
+    pp.sto_emax[:] = np.where(kind == 1, pp.sto_pmax * 0.3,                          # fills in a fraction of a step
+                              np.where(kind == 2, pp.sto_pmax * 3 * T, pp.sto_pmax * rng.integers(1, 6, size=S)))
+    P = rng.uniform(0, 1, size=(G, T)) * pp.gen_pmax[:, None]
+    C = np.zeros((S, T))
+    D = np.zeros((S, T))
+    for s in range(S):                       # random walk inside the level band (so that (D, C) is feasible)
+        e = 0.0
+        for t in range(T):
+            c = rng.uniform(0, min(pp.sto_pmax[s], pp.sto_emax[s] - e)) if rng.random() < 0.5 else 0.0
+            d = rng.uniform(0, min(pp.sto_pmax[s], e + c)) if rng.random() < 0.5 else 0.0
+            C[s, t], D[s, t] = c, d
+            e += c - d
+    lam = rng.normal(0, 25, size=T) - 15.0
+    return pp, P, D, C, lam
+
+
+@pytest.mark.parametrize("T,n_cases", [(5, 12), (24, 10), (33, 6), (96, 4), (150, 3)])
+def test_hip_storage_kernels_on_random_states(hip_api, oracle_api, T, n_cases):
+    """Cold scan kernel (first step after set_state) and warm-start kernel (the steps after) against the
+    oracle's exact mode — and against the literally assembled QPs on the short horizons — from random
+    feasible states with awkward storages: zero marginal cost, tiny or never-binding level bands,
+    strong and weak penalties, non-unit prox weight."""
+    rng = np.random.default_rng(1000 + T)
+    for i in range(n_cases):
+        pp, P, D, C, lam = _random_storage_case(rng, T)
+        params = dict(gamma=float(rng.choice([0.003, 0.05, 0.3, 1.0])), w_prox=float(rng.choice([1.0, 0.25, 4.0])), eps=0.0)
+        h = make_engine(hip_api, pp, **params)
+        engines = [h, make_engine(oracle_api, pp, mode=1, **params)]
+        if T <= 5:
+            engines.append(make_engine(oracle_api, pp, mode=0, **params))     # the literal QPs as a third opinion
+        for e in engines:
+            e.set_state(P=P, D=D, C_=C, lam=lam, iteration=7)
+        for step in range(4):                 # step 0: cold scan; steps 1-3: warm start where its certificate holds
+            for e in engines:
+                e.iterate(1)
+            st = [state_of(e) for e in engines]
+            worst, where = max_diff(st[0], st[1], keys=["D", "C", "E", "P", "lam", "inj"])
+            assert worst < 1e-8, (T, i, step, where, worst)
+            if T <= 5:                        # interior-point noise of the literal mode: 1e-7 .. 1e-6 per step
+                worst, where = max_diff(st[0], st[2], keys=["D", "C", "E", "P", "lam", "inj"])
+                assert worst < 2e-5, (T, i, step, where, worst)
+        assert h.solver_failures() == 0
