@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-iters", type=int, default=32)
     ap.add_argument("--overlap", action="store_true", help="fork the storage kernel onto a side stream")
+    ap.add_argument("--no-also", action="store_true", help="skip the short side runs of the other single-GPU workloads")
     ap.add_argument("--force-sharded", action="store_true", help="debug: drive the sharded (all-reduce) path even on one rank")
     args = ap.parse_args()
 
@@ -235,6 +236,27 @@ def main():
             out["time_to_1e-3_residual"] = {"seconds": t2 if conv2 else None, "iterations": done2, "converged": bool(conv2),
                                             "iteration_cap": budget, "total_cost": e2.get_consensus()[4]}
             e2.close()
+        if not sharded and not args.no_also and args.scale == 1.0:
+            # the other BASELINE configurations that fit one GPU, same engine, short runs (reported, not the metric)
+            also = []
+            for wl in ("config1", "config4", "config2"):
+                if wl == args.workload:
+                    continue
+                ppx = synth.baseline_config(WORKLOADS[wl][0])
+                Ax = ppx.G + ppx.S
+                ex = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=1.0 / Ax, eps=0.0, device=local_rank),
+                                  **ppx.engine_kwargs())
+                ex.iterate(args.warmup)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ex.iterate(200)
+                tx = time.perf_counter() - t0
+                gb, sb, shb = algorithmic_bytes(ppx.G, ppx.S, ppx.T, ppx.N, ppx.L)
+                also.append({"workload": wl, "agents": Ax, "timesteps": ppx.T, "iters_per_sec": 200 / tx,
+                             "agent_updates_per_sec": Ax * 200 / tx, "ms_per_step": 1e3 * tx / 200,
+                             "whole_iteration_GBps": (gb + sb + shb) / (tx / 200) / 1e9})
+                ex.close()
+            out["also"] = also
         if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pp, gamma)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

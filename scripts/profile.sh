@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/prof_$W
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $ROOT
-ARGS="bench.py --workload $W --no-cpu-baseline"      # bench.py defaults: 48 warm-up + 400 timed + 32 event-timed iterations
+ARGS="bench.py --workload $W --no-cpu-baseline --no-also"      # bench.py defaults: 48 warm-up + 400 timed + 32 event-timed iterations
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.json 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.json 2> $OUT/write.err
