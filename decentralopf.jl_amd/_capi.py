@@ -51,6 +51,7 @@ class DopfTiming(C.Structure):
 F_NO_GRAPH = 1
 F_OVERLAP_AGENTS = 2
 F_NO_WARM_START = 4
+F_NO_ROW_SKIP = 8
 
 
 class DopfError(RuntimeError):

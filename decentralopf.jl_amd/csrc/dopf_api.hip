@@ -251,6 +251,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         int chunk = std::max(R, (G + 2047) / 2048);
         chunk = (chunk + R - 1) / R * R;
         make_items(gnode, N, chunk, gitems, ngb, ngib);
+        v.genSkip = (v.genTT2 > 0 && chunk >= 8 * R && !(q->flags & DOPF_F_NO_ROW_SKIP)) ? 1 : 0;
         const int NG = S > 0 ? 256 / lc.stoLPS : 1;
         int schunk = std::max(NG, (S + 2047) / 2048);
         schunk = (schunk + NG - 1) / NG * NG;
@@ -275,6 +276,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     TRY(dev_upload(c, &v.node_gen_beg, ngb)); TRY(dev_upload(c, &v.node_sto_beg, nsb));
     TRY(dev_upload(c, &v.node_gitem_beg, ngib)); TRY(dev_upload(c, &v.node_sitem_beg, nsib));
     TRY(dev_alloc(c, &v.P, (size_t)G * T));
+    TRY(dev_alloc(c, &v.gen_state, G));            // zero = "all zero", which is what P is now
     TRY(dev_alloc(c, &v.D, (size_t)S * T)); TRY(dev_alloc(c, &v.C, (size_t)S * T)); TRY(dev_alloc(c, &v.E, (size_t)S * T));
     if (L > 0) { TRY(dev_alloc(c, &v.dltG, (size_t)G * T)); TRY(dev_alloc(c, &v.dltS, (size_t)S * T)); }
     TRY(dev_alloc(c, &v.lam, T)); TRY(dev_alloc(c, &v.mu, LT)); TRY(dev_alloc(c, &v.rho, LT));
@@ -607,6 +609,10 @@ int dopf_set_state(dopf_ctx *c, const double *P, const double *D, const double *
     if ((rc = up(v.mu, mu, LT))) return rc;
     if ((rc = up(v.rho, rho, LT))) return rc;
     if (v.S > 0) HIPCHK(c, hipMemset(v.nu_valid, 0, sizeof(int) * v.S));   // stored prices no longer match the state
+    if (v.G > 0 && P) {                                                     // nor do the row summaries of P
+        std::vector<int> mixed(v.G, 2);
+        HIPCHK(c, hipMemcpy(v.gen_state, mixed.data(), sizeof(int) * v.G, hipMemcpyHostToDevice));
+    }
     Status st{};
     HIPCHK(c, hipMemcpy(&st, v.st, sizeof st, hipMemcpyDeviceToHost));
     st.iteration = iteration;

@@ -44,6 +44,7 @@ struct DevView {
     int N, L, T, G, S, M2;          // M2 = 2L
     int nGenItems, nStoItems;
     int genTT, genR;                // generator block tiling: TT = min(T, 512) timesteps x R agents
+    int genSkip;                    // pair kernel with row skipping (blocks sweep >= 8 passes of agents)
     int genTT2, genR2;              // pair kernel (copper plate, even T <= 1024): T/2 double2 columns x R2 agents; 0 = off
     int reduceRB;                   // reduce blocks per node (two-level fixed-order sum)
     int use_warm;                   // storage warm-start kernel runs first; the scan kernel serves its failures
@@ -58,6 +59,7 @@ struct DevView {
     const int *node_gitem_beg, *node_sitem_beg;     // N+1 each: item ranges per node
     // primal state
     double *P, *D, *C, *E, *dltG, *dltS;
+    int *gen_state;                 // per generator: 0 = P all zero, 1 = all at pmax, 2 = mixed (pair kernel's row skipping)
     // duals and consensus state
     double *lam, *mu, *rho, *lam_used, *mu_used, *rho_used;
     double *inj, *s, *flow, *avgU, *avgK, *price;

@@ -122,8 +122,8 @@ __global__ __launch_bounds__(512) void k_gen_update_pair(DevView v)
     double cost = 0.0, acc0 = 0.0, acc1 = 0.0;
     if (r < R) {
         const int t = 2 * tt;
-        const double sh0 = (v.price[it.node + N * t] + gam * v.s[t]) * inv;
-        const double sh1 = (v.price[it.node + N * (t + 1)] + gam * v.s[t + 1]) * inv;
+        const double sh0 = fma(gam, v.s[t], v.price[it.node + N * t]) * inv;
+        const double sh1 = fma(gam, v.s[t + 1], v.price[it.node + N * (t + 1)]) * inv;
         double2 *P2 = reinterpret_cast<double2 *>(v.P);
         const size_t half = (size_t)(T >> 1);
 #pragma unroll 4
@@ -132,13 +132,105 @@ __global__ __launch_bounds__(512) void k_gen_update_pair(DevView v)
             const double mc = v.gen_mc[g], pm = v.gen_pmax[g];
             const double2 p0 = P2[e];
             double2 pn;
-            pn.x = clampd(p0.x - (mc * inv + sh0), 0.0, pm);
-            pn.y = clampd(p0.y - (mc * inv + sh1), 0.0, pm);
+            // explicit fma: the row-skipping variant below must round exactly like this sweep
+            pn.x = clampd(p0.x - fma(mc, inv, sh0), 0.0, pm);
+            pn.y = clampd(p0.y - fma(mc, inv, sh1), 0.0, pm);
             P2[e] = pn;
             acc0 += pn.x; acc1 += pn.y;
-            cost += mc * (pn.x + pn.y);
+            cost = fma(mc, pn.x + pn.y, cost);
         }
     }
+    red[0][tid] = acc0; red[1][tid] = acc1;
+    __syncthreads();
+    if (r == 0 && tt < TT) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int q = 0; q < R; ++q) { s0 += red[0][q * TT + tt]; s1 += red[1][q * TT + tt]; }
+        v.part_ginj[(size_t)blockIdx.x * T + 2 * tt] = s0;
+        v.part_ginj[(size_t)blockIdx.x * T + 2 * tt + 1] = s1;
+    }
+    __syncthreads();
+    red[0][tid] = cost;
+    __syncthreads();
+    for (int sft = 256; sft > 0; sft >>= 1) {
+        if (tid < sft) red[0][tid] += red[0][tid + sft];
+        __syncthreads();
+    }
+    if (tid == 0) v.part_gcost[blockIdx.x] = red[0][0];
+}
+
+// Row skipping variant (used when a block sweeps many agents, so that its fixed cost is amortised): in a
+// settled dispatch two thirds of the generators sit at 0 or at pmax for ALL timesteps and stay there. A word
+// per generator remembers "all zero" / "all at pmax" / "mixed"; an all-zero row stays all zero iff
+// mc/(w+gamma) + min_t shift_t >= 0, an all-pmax row stays iff mc/(w+gamma) + max_t shift_t <= 0 (the update
+// then clamps every element back onto the same bound), so such a row is neither read nor written — its
+// contribution to the sums is 0 or pmax. Results are identical to the full sweep, bit for bit.
+__global__ __launch_bounds__(512) void k_gen_update_pair_skip(DevView v)
+{
+    if (v.st->halt) return;
+    __shared__ double red[2][512];
+    __shared__ int flg[2][512];
+    const Item it = v.gen_items[blockIdx.x];
+    const int T = v.T, N = v.N, TT = v.genTT2, R = v.genR2;     // TT = T/2 pair columns
+    const int tid = threadIdx.x;
+    const int r = tid / TT, tt = tid - r * TT;
+    const double w = v.w_prox, gam = v.gamma;
+    const double inv = 1.0 / (w + gam);
+    double cost = 0.0, acc0 = 0.0, acc1 = 0.0;
+    double sh0 = 0.0, sh1 = 0.0;
+    if (r < R) {
+        const int t = 2 * tt;
+        sh0 = fma(gam, v.s[t], v.price[it.node + N * t]) * inv;
+        sh1 = fma(gam, v.s[t + 1], v.price[it.node + N * (t + 1)]) * inv;
+    }
+    // min and max of the shift over the horizon (same for every agent of the item)
+    red[0][tid] = (r == 0 && tt < TT) ? fmin(sh0, sh1) : INFINITY;
+    red[1][tid] = (r == 0 && tt < TT) ? fmax(sh0, sh1) : -INFINITY;
+    flg[0][tid] = 3; flg[1][tid] = 3;
+    __syncthreads();
+    for (int sft = 256; sft > 0; sft >>= 1) {
+        if (tid < sft) { red[0][tid] = fmin(red[0][tid], red[0][tid + sft]); red[1][tid] = fmax(red[1][tid], red[1][tid + sft]); }
+        __syncthreads();
+    }
+    const double smin = red[0][0], smax = red[1][0];
+    __syncthreads();
+
+    double2 *P2 = reinterpret_cast<double2 *>(v.P);
+    const size_t half = (size_t)(T >> 1);
+    const int nPass = (it.a1 - it.a0 + R - 1) / R;
+    for (int p = 0; p < nPass; ++p) {
+        const int g = it.a0 + p * R + r;
+        const bool on = r < R && g < it.a1;
+        bool full = false;
+        if (on) {
+            const double mc = v.gen_mc[g], pm = v.gen_pmax[g];
+            const int stt = v.gen_state[g];                 // 0 all zero, 1 all at pmax, 2 mixed
+            // fma(mc, inv, .) is monotone in its addend, so its extremes over t are at smin / smax
+            if (stt == 0 && fma(mc, inv, smin) >= 0.0) {
+                // stays all zero: nothing to read, write or add
+            } else if (stt == 1 && fma(mc, inv, smax) <= 0.0) {
+                acc0 += pm; acc1 += pm; cost = fma(mc, pm + pm, cost);      // stays all at pmax
+            } else {
+                full = true;
+                const size_t e = (size_t)g * half + tt;
+                const double2 p0 = P2[e];
+                double2 pn;
+                pn.x = clampd(p0.x - fma(mc, inv, sh0), 0.0, pm);
+                pn.y = clampd(p0.y - fma(mc, inv, sh1), 0.0, pm);
+                P2[e] = pn;
+                acc0 += pn.x; acc1 += pn.y;
+                cost = fma(mc, pn.x + pn.y, cost);
+                const int bits = ((pn.x == 0.0 && pn.y == 0.0) ? 1 : 0) | ((pn.x == pm && pn.y == pm) ? 2 : 0);
+                if (bits != 3) atomicAnd(&flg[p & 1][r], bits);
+            }
+        }
+        __syncthreads();
+        if (full && tt == 0) {
+            const int bits = flg[p & 1][r];
+            v.gen_state[g] = (bits & 1) ? 0 : ((bits & 2) ? 1 : 2);
+        }
+        if (tt == 0 && r < R) flg[p & 1][r] = 3;              // free again two passes later
+    }
+    __syncthreads();
     red[0][tid] = acc0; red[1][tid] = acc1;
     __syncthreads();
     if (r == 0 && tt < TT) {
@@ -161,6 +253,7 @@ void launch_gen_update(const DevView &v, hipStream_t s)
 {
     if (v.nGenItems == 0) return;
     if (v.L > 0) hipLaunchKernelGGL(k_gen_update<true>, dim3(v.nGenItems), dim3(512), 0, s, v);
+    else if (v.genTT2 > 0 && v.genSkip) hipLaunchKernelGGL(k_gen_update_pair_skip, dim3(v.nGenItems), dim3(512), 0, s, v);
     else if (v.genTT2 > 0) hipLaunchKernelGGL(k_gen_update_pair, dim3(v.nGenItems), dim3(512), 0, s, v);
     else hipLaunchKernelGGL(k_gen_update<false>, dim3(v.nGenItems), dim3(512), 0, s, v);
 }

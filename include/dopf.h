@@ -99,6 +99,7 @@ typedef struct dopf_params {
                                    kernel (default: one stream, kernels back to back — the per-kernel
                                    durations then mean the same in every tool)                        */
 
+#define DOPF_F_NO_ROW_SKIP   8  /* generators: always sweep every row of P (no skipping of saturated rows)    */
 #define DOPF_F_NO_WARM_START 4  /* storages: always the cold price-threshold scan (no warm-start kernel) */
 
 /* Fill q with the reference's defaults (values above). */
