@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-iters", type=int, default=32)
     ap.add_argument("--overlap", action="store_true", help="fork the storage kernel onto a side stream")
+    ap.add_argument("--flags", type=int, default=0, help="DOPF_F_* bits (include/dopf.h), e.g. 16 = separate generator/storage launches")
     ap.add_argument("--no-also", action="store_true", help="skip the short side runs of the other single-GPU workloads")
     ap.add_argument("--force-sharded", action="store_true", help="debug: drive the sharded (all-reduce) path even on one rank")
     args = ap.parse_args()
@@ -133,7 +134,7 @@ def main():
 
     if not sharded:
         eng = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, eps=0.0, device=local_rank,
-                                                                        flags=_capi.F_OVERLAP_AGENTS if args.overlap else 0),
+                                                                        flags=args.flags | (_capi.F_OVERLAP_AGENTS if args.overlap else 0)),
                            **pp.engine_kwargs())
         step = lambda n: eng.iterate(n)
         sync = lambda: eng.sync()
@@ -199,39 +200,53 @@ def main():
             peak = 8000.0        # GB/s, HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
             # an event pair costs a fixed few microseconds even with nothing between (empty_ms): net it out
             k_ms = max(timing["gen_ms"] - timing["empty_ms"], 1e-6)
-            ach = (gen_b + shared_b) / (k_ms * 1e-3) / 1e9
+            fused = bool(timing.get("agents_fused"))
+            pair = pp.L == 0 and pp.T % 2 == 0
+            if fused:       # ONE launch does every x-update: generators and storages
+                kname, alg_b = "k_agents", gen_b + sto_b + shared_b
+            else:
+                kname, alg_b = ("k_gen_update_pair" if pair else "k_gen_update"), gen_b + shared_b
+            ach = alg_b / (k_ms * 1e-3) / 1e9
             traffic = None       # HBM bytes per launch from the committed PMC passes (scripts/profile.sh)
             pmc_file = os.path.join(ROOT, "profiles", "r01_pmc.json")
             if os.path.exists(pmc_file):
                 recs = json.load(open(pmc_file)).get(args.workload, {})
-                rec = recs.get("k_gen_update_pair_skip") or recs.get("k_gen_update_pair") or recs.get("k_gen_update")
+                rec = next((r for k, r in sorted(recs.items()) if k.startswith(kname) and r.get("FETCH_SIZE") is not None), None)
                 if rec:        # gfx950: FETCH_SIZE counts half of a streaming read (MI355X_MICROARCH.md, HBM); unit KiB
                     traffic = (2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0
-            out["roofline"] = {"bound": "hbm", "kernel": "k_gen_update_pair" if (pp.L == 0 and pp.T % 2 == 0) else "k_gen_update", "achieved": ach, "peak": peak,
+            out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": peak,
                                "unit": "GB/s", "frac": ach / peak, "traffic": traffic,
-                               "algorithmic_bytes_per_launch": gen_b + shared_b,
+                               "algorithmic_bytes_per_launch": alg_b,
                                "kernel_ms": k_ms, "kernel_ms_with_event_overhead": timing["gen_ms"]}
             if traffic is not None:
                 out["roofline"]["traffic_GBps"] = traffic / (k_ms * 1e-3) / 1e9
                 out["roofline"]["traffic_frac_of_peak"] = out["roofline"]["traffic_GBps"] / peak
-            row_skip = pp.L == 0 and pp.T % 2 == 0 and max(512 // (pp.T // 2), -(-pp.G // 2048)) >= 8 * (512 // (pp.T // 2))
+            bs = 256 if fused else 512
+            rows = bs // (pp.T // 2) if pair else 1
+            row_skip = pair and not (args.flags & _capi.F_NO_ROW_SKIP) and max(rows, -(-pp.G // 2048)) >= 8 * rows    # as dopf_create decides
+            if fused:
+                out["roofline"]["what"] = ("all x-updates of an iteration in one launch: generator blocks stream P (HBM bound), storage "
+                                           "blocks run the warm-started SoC solve (latency/VALU bound) on the same CUs")
             if row_skip:
-                out["roofline"]["kernel"] = "k_gen_update_pair_skip"
+                if not fused:
+                    out["roofline"]["kernel"] = "k_gen_update_pair_skip"
                 out["roofline"]["note"] = ("rows of P that sit on a bound for all timesteps and provably stay there are neither read nor "
-                                           "written (bit-identical results), so the kernel moves fewer bytes than the 16T+20 B per-update "
-                                           "model: `achieved`/`frac` (algorithmic bytes / time) can exceed the HBM peak; `traffic` is what moved")
-            out["kernels_ms"] = {k: v for k, v in timing.items() if k != "iters"}
-            s_ms = max(timing["sto_ms"] - timing["empty_ms"], 1e-6)
-            out["storage_kernel"] = {"kernel": "k_sto_warm + k_sto_update", "bound": "fp64 VALU (segmented Newton + certificate; scan fallback), not HBM",
-                                     "algorithmic_bytes_per_launch": sto_b, "kernel_ms": s_ms,
-                                     "achieved_GBps": sto_b / s_ms * 1e-6}
+                                           "written (bit-identical results), so the launch moves fewer bytes than the 16T+20 B per-update "
+                                           "model: `achieved`/`frac` (algorithmic bytes / time) can exceed what `traffic` shows moved")
+            out["kernels_ms"] = {k: v for k, v in timing.items() if k not in ("iters", "agents_fused")}
+            out["agents_fused"] = fused
+            if not fused:
+                s_ms = max(timing["sto_ms"] - timing["empty_ms"], 1e-6)
+                out["storage_kernel"] = {"kernel": "k_sto_warm + k_sto_update", "bound": "fp64 VALU (segmented Newton + certificate; scan fallback), not HBM",
+                                         "algorithmic_bytes_per_launch": sto_b, "kernel_ms": s_ms,
+                                         "achieved_GBps": sto_b / s_ms * 1e-6}
             whole = (gen_b + sto_b + shared_b) / (dt / args.steps) / 1e9
             out["whole_iteration_GBps"] = whole
             out["whole_iteration_frac_of_peak"] = whole / peak
         if not sharded:
             # the other half of BASELINE's metric: wall time until every |dual change| < 1e-3, from the zero state
             budget = int(max(64, min(100000, 10.0 * args.steps / dt)))     # at most ~10 s of iterations
-            e2 = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, eps=1e-3, max_iters=budget, device=local_rank),
+            e2 = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, eps=1e-3, max_iters=budget, device=local_rank, flags=args.flags),
                               **pp.engine_kwargs())
             torch.cuda.synchronize()
             t0 = time.perf_counter()

@@ -45,13 +45,15 @@ class DopfParams(C.Structure):
 class DopfTiming(C.Structure):
     _fields_ = [("tables_ms", C.c_double), ("gen_ms", C.c_double), ("sto_ms", C.c_double),
                 ("slack_ms", C.c_double), ("reduce_ms", C.c_double), ("dual_ms", C.c_double),
-                ("iter_ms", C.c_double), ("empty_ms", C.c_double), ("iters", C.c_int32)]
+                ("iter_ms", C.c_double), ("empty_ms", C.c_double), ("iters", C.c_int32),
+                ("agents_fused", C.c_int32)]
 
 
 F_NO_GRAPH = 1
 F_OVERLAP_AGENTS = 2
 F_NO_WARM_START = 4
 F_NO_ROW_SKIP = 8
+F_NO_FUSE = 16
 
 
 class DopfError(RuntimeError):

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -108,7 +109,9 @@ void enqueue_local(dopf_ctx *c)
     const DevView &v = c->v;
     launch_tables(v, c->main);
     const bool fork = v.nGenItems > 0 && v.nStoItems > 0 && (c->q.flags & DOPF_F_OVERLAP_AGENTS);
-    if (fork) {
+    if (v.fuseAgents) {
+        launch_agents_fused(v, c->lc, c->main);
+    } else if (fork) {
         hipEventRecord(c->evFork, c->main);
         hipStreamWaitEvent(c->side, c->evFork, 0);
         launch_sto_update(v, c->lc, c->side);
@@ -228,14 +231,28 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     v.genTT = std::min(T, 512);
     v.genR = 512 / v.genTT;
     v.genTT2 = (L == 0 && T % 2 == 0 && T / 2 <= 512) ? T / 2 : 0;
-    v.genR2 = v.genTT2 ? 512 / v.genTT2 : 0;
+    v.fuseAgents = (v.genTT2 > 0 && v.genTT2 <= 256 && G > 0 && S > 0 && v.use_warm &&
+                    !(q->flags & (DOPF_F_NO_FUSE | DOPF_F_OVERLAP_AGENTS))) ? 1 : 0;
+    if (v.fuseAgents) {
+        // one launch for all agents pays while its fixed cost matters and every storage block is resident from
+        // the start (3 blocks of 256 per CU at the storage code's register count); see k_agents
+        const int ng = 256 / lc.stoLPS;
+        const int sch = (std::max(ng, (S + 2047) / 2048) + ng - 1) / ng * ng;
+        const long long sto_blocks = (S + sch - 1) / sch + N - 1;
+        if (sto_blocks > 3 * 256 || (long long)G * T > (8ll << 20)) v.fuseAgents = 0;
+    }
+    v.genR2 = v.genTT2 ? (v.fuseAgents ? 256 : 512) / v.genTT2 : 0;
 
     // sort agents by node (stable), remember the permutation
     c->gen_perm.resize(G);
     c->sto_perm.resize(S);
     std::iota(c->gen_perm.begin(), c->gen_perm.end(), 0);
     std::iota(c->sto_perm.begin(), c->sto_perm.end(), 0);
-    std::stable_sort(c->gen_perm.begin(), c->gen_perm.end(), [&](int a, int b) { return p->gen_node[a] < p->gen_node[b]; });
+    // generators: by node, then by marginal cost — a settled dispatch parks the cheap ones at pmax and the dear
+    // ones at 0, so the rows the generator kernel may skip (and the ones it must stream) become contiguous
+    std::stable_sort(c->gen_perm.begin(), c->gen_perm.end(), [&](int a, int b) {
+        return p->gen_node[a] != p->gen_node[b] ? p->gen_node[a] < p->gen_node[b] : p->gen_mc[a] < p->gen_mc[b];
+    });
     std::stable_sort(c->sto_perm.begin(), c->sto_perm.end(), [&](int a, int b) { return p->sto_node[a] < p->sto_node[b]; });
     std::vector<double> gmc(G), gpm(G), smc(S), spm(S), sem(S);
     std::vector<int> gnode(G), snode(S);
@@ -383,10 +400,11 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
         hipStream_t ss = fork ? c->side : c->main;
         if (fork) { hipEventRecord(c->evFork, c->main); hipStreamWaitEvent(c->side, c->evFork, 0); }
         hipEventRecord(e[E_G0], c->main);
-        launch_gen_update(v, c->main);
+        if (v.fuseAgents) launch_agents_fused(v, c->lc, c->main);
+        else launch_gen_update(v, c->main);
         hipEventRecord(e[E_G1], c->main);
         hipEventRecord(e[E_S0], ss);
-        launch_sto_update(v, c->lc, ss);
+        if (!v.fuseAgents) launch_sto_update(v, c->lc, ss);
         hipEventRecord(e[E_S1], ss);
         if (fork) { hipEventRecord(c->evJoin, c->side); hipStreamWaitEvent(c->main, c->evJoin, 0); }
         hipEventRecord(e[E_K0], c->main);
@@ -420,6 +438,7 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
     out->tables_ms *= inv; out->gen_ms *= inv; out->sto_ms *= inv; out->slack_ms *= inv;
     out->reduce_ms *= inv; out->dual_ms *= inv; out->iter_ms *= inv; out->empty_ms *= inv;
     out->iters = n_iters;
+    out->agents_fused = v.fuseAgents;
     for (auto &e : ev) hipEventDestroy(e);
     return DOPF_OK;
 }

@@ -47,6 +47,7 @@ struct DevView {
     int genSkip;                    // pair kernel with row skipping (blocks sweep >= 8 passes of agents)
     int genTT2, genR2;              // pair kernel (copper plate, even T <= 1024): T/2 double2 columns x R2 agents; 0 = off
     int reduceRB;                   // reduce blocks per node (two-level fixed-order sum)
+    int fuseAgents;                 // copper plate, even T: generators + storages in one launch (k_agents, 256-thread blocks)
     int use_warm;                   // storage warm-start kernel runs first; the scan kernel serves its failures
     int max_iters;
     double gamma, w_flow, w_prox, eps, mask_thr, invA;
@@ -86,6 +87,7 @@ struct Launch {
 // kernels_agents.hip
 void launch_gen_update(const DevView &v, hipStream_t s);
 void launch_sto_update(const DevView &v, const Launch &lc, hipStream_t s);
+void launch_agents_fused(const DevView &v, const Launch &lc, hipStream_t s);
 bool sto_config_supported(int T, Launch *lc);
 // kernels_consensus.hip
 void launch_tables(const DevView &v, hipStream_t s);

@@ -109,11 +109,11 @@ __global__ __launch_bounds__(512) void k_gen_update(DevView v)
 
 // Copper plate, even T: each thread owns TWO consecutive timesteps of an agent, so every P access is a
 // 16-byte-per-lane double2 (the widest coalesced form), half as many load/store instructions per byte.
-__global__ __launch_bounds__(512) void k_gen_update_pair(DevView v)
+template <int BS>
+__device__ __forceinline__ void gen_pair_body(const DevView &v, const int blk)
 {
-    if (v.st->halt) return;
-    __shared__ double red[2][512];
-    const Item it = v.gen_items[blockIdx.x];
+    __shared__ double red[2][BS];
+    const Item it = v.gen_items[blk];
     const int T = v.T, N = v.N, TT = v.genTT2, R = v.genR2;     // TT = T/2 pair columns
     const int tid = threadIdx.x;
     const int r = tid / TT, tt = tid - r * TT;
@@ -145,17 +145,23 @@ __global__ __launch_bounds__(512) void k_gen_update_pair(DevView v)
     if (r == 0 && tt < TT) {
         double s0 = 0.0, s1 = 0.0;
         for (int q = 0; q < R; ++q) { s0 += red[0][q * TT + tt]; s1 += red[1][q * TT + tt]; }
-        v.part_ginj[(size_t)blockIdx.x * T + 2 * tt] = s0;
-        v.part_ginj[(size_t)blockIdx.x * T + 2 * tt + 1] = s1;
+        v.part_ginj[(size_t)blk * T + 2 * tt] = s0;
+        v.part_ginj[(size_t)blk * T + 2 * tt + 1] = s1;
     }
     __syncthreads();
     red[0][tid] = cost;
     __syncthreads();
-    for (int sft = 256; sft > 0; sft >>= 1) {
+    for (int sft = BS / 2; sft > 0; sft >>= 1) {
         if (tid < sft) red[0][tid] += red[0][tid + sft];
         __syncthreads();
     }
-    if (tid == 0) v.part_gcost[blockIdx.x] = red[0][0];
+    if (tid == 0) v.part_gcost[blk] = red[0][0];
+}
+
+__global__ __launch_bounds__(512) void k_gen_update_pair(DevView v)
+{
+    if (v.st->halt) return;
+    gen_pair_body<512>(v, blockIdx.x);
 }
 
 // Row skipping variant (used when a block sweeps many agents, so that its fixed cost is amortised): in a
@@ -164,12 +170,12 @@ __global__ __launch_bounds__(512) void k_gen_update_pair(DevView v)
 // mc/(w+gamma) + min_t shift_t >= 0, an all-pmax row stays iff mc/(w+gamma) + max_t shift_t <= 0 (the update
 // then clamps every element back onto the same bound), so such a row is neither read nor written — its
 // contribution to the sums is 0 or pmax. Results are identical to the full sweep, bit for bit.
-__global__ __launch_bounds__(512) void k_gen_update_pair_skip(DevView v)
+template <int BS>
+__device__ __forceinline__ void gen_pair_skip_body(const DevView &v, const int blk)
 {
-    if (v.st->halt) return;
-    __shared__ double red[2][512];
-    __shared__ int flg[2][512];
-    const Item it = v.gen_items[blockIdx.x];
+    __shared__ double red[2][BS];
+    __shared__ int flg[2][BS];
+    const Item it = v.gen_items[blk];
     const int T = v.T, N = v.N, TT = v.genTT2, R = v.genR2;     // TT = T/2 pair columns
     const int tid = threadIdx.x;
     const int r = tid / TT, tt = tid - r * TT;
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(512) void k_gen_update_pair_skip(DevView v)
     red[1][tid] = (r == 0 && tt < TT) ? fmax(sh0, sh1) : -INFINITY;
     flg[0][tid] = 3; flg[1][tid] = 3;
     __syncthreads();
-    for (int sft = 256; sft > 0; sft >>= 1) {
+    for (int sft = BS / 2; sft > 0; sft >>= 1) {
         if (tid < sft) { red[0][tid] = fmin(red[0][tid], red[0][tid + sft]); red[1][tid] = fmax(red[1][tid], red[1][tid + sft]); }
         __syncthreads();
     }
@@ -236,17 +242,23 @@ __global__ __launch_bounds__(512) void k_gen_update_pair_skip(DevView v)
     if (r == 0 && tt < TT) {
         double s0 = 0.0, s1 = 0.0;
         for (int q = 0; q < R; ++q) { s0 += red[0][q * TT + tt]; s1 += red[1][q * TT + tt]; }
-        v.part_ginj[(size_t)blockIdx.x * T + 2 * tt] = s0;
-        v.part_ginj[(size_t)blockIdx.x * T + 2 * tt + 1] = s1;
+        v.part_ginj[(size_t)blk * T + 2 * tt] = s0;
+        v.part_ginj[(size_t)blk * T + 2 * tt + 1] = s1;
     }
     __syncthreads();
     red[0][tid] = cost;
     __syncthreads();
-    for (int sft = 256; sft > 0; sft >>= 1) {
+    for (int sft = BS / 2; sft > 0; sft >>= 1) {
         if (tid < sft) red[0][tid] += red[0][tid + sft];
         __syncthreads();
     }
-    if (tid == 0) v.part_gcost[blockIdx.x] = red[0][0];
+    if (tid == 0) v.part_gcost[blk] = red[0][0];
+}
+
+__global__ __launch_bounds__(512) void k_gen_update_pair_skip(DevView v)
+{
+    if (v.st->halt) return;
+    gen_pair_skip_body<512>(v, blockIdx.x);
 }
 
 void launch_gen_update(const DevView &v, hipStream_t s)
@@ -460,20 +472,21 @@ struct StoAgent {
     double mc, pm, em;
 };
 
+// `item_fail`: number of storages of this item the warm start left over (block-uniform); < 0 = read it
 template <int LPS, int NCH, bool LINES>
-__global__ __launch_bounds__(256) void k_sto_update(DevView v)
+__device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, int item_fail)
 {
-    if (v.st->halt) return;
     constexpr int NG = 256 / LPS;
     __shared__ double red[NG * LPS * NCH];
     __shared__ double redc[256];
     const int tid = threadIdx.x, lane = tid & 63, li = tid & (LPS - 1), grp = tid / LPS;
     const int gbase = lane & ~(LPS - 1);
-    const Item it = v.sto_items[blockIdx.x];
+    const Item it = v.sto_items[blk];
     const int T = v.T, N = v.N;
-    if (v.use_warm && v.item_fail[blockIdx.x] == 0) {      // the warm-start kernel solved this whole item
-        for (int t = tid; t < T; t += 256) v.part_sinj[(size_t)blockIdx.x * T + t] = 0.0;
-        if (tid == 0) v.part_scost[blockIdx.x] = 0.0;
+    if (item_fail < 0) item_fail = v.item_fail[blk];
+    if (v.use_warm && item_fail == 0) {      // the warm start solved this whole item
+        for (int t = tid; t < T; t += 256) v.part_sinj[(size_t)blk * T + t] = 0.0;
+        if (tid == 0) v.part_scost[blk] = 0.0;
         return;
     }
     const double w = v.w_prox, gam = v.gamma;
@@ -741,7 +754,7 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
             if (t < T) {
                 double sum = 0.0;
                 for (int g2 = 0; g2 < NG; ++g2) sum += red[(g2 * LPS + li) * NCH + c];
-                v.part_sinj[(size_t)blockIdx.x * T + t] = sum;
+                v.part_sinj[(size_t)blk * T + t] = sum;
             }
         }
     }
@@ -749,13 +762,20 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
         if (tid < sft) redc[tid] += redc[tid + sft];
         __syncthreads();
     }
-    if (tid == 0) v.part_scost[blockIdx.x] = redc[0];
+    if (tid == 0) v.part_scost[blk] = redc[0];
     if (fails) atomicAdd(&v.st->solver_fail, fails);
 #ifdef DOPF_STATS
     if (st_scans) atomicAdd(&v.st->dbg_scans, st_scans);
     if (st_loops) atomicAdd(&v.st->dbg_wave_loops, st_loops);
     if (st_events) atomicAdd(&v.st->dbg_events, st_events);
 #endif
+}
+
+template <int LPS, int NCH, bool LINES>
+__global__ __launch_bounds__(256) void k_sto_update(DevView v)
+{
+    if (v.st->halt) return;
+    sto_cold_body<LPS, NCH, LINES>(v, blockIdx.x, -1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -840,17 +860,17 @@ __device__ __forceinline__ double next_lane(double x)
     return dppd<0x130, 0xF>(x, x);                     // wave_shl:1
 }
 
+// returns the number of storages of the item left to the scan (block-uniform)
 template <int LPS, int NCH, bool LINES>
-__global__ __launch_bounds__(256) void k_sto_warm(DevView v)
+__device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
 {
-    if (v.st->halt) return;
     constexpr int NG = 256 / LPS, TP = LPS * NCH;
     __shared__ double red[NG * TP];          // also nuL during the solve
     __shared__ double baseL[NG * TP];
     __shared__ int keyL[NG * TP];
     __shared__ double redc[256];
     const int tid = threadIdx.x, lane = tid & 63, li = tid & (LPS - 1), grp = tid / LPS;
-    const Item it = v.sto_items[blockIdx.x];
+    const Item it = v.sto_items[blk];
     const int T = v.T, N = v.N;
     const double w = v.w_prox, gam = v.gamma;
     const double a0 = w + gam, ia0 = 1.0 / a0, idet0 = 1.0 / (a0 * a0 - gam * gam), s20 = 2.0 / (a0 + gam);
@@ -1104,7 +1124,7 @@ __global__ __launch_bounds__(256) void k_sto_warm(DevView v)
             if (t < T) {
                 double sum = 0.0;
                 for (int g2 = 0; g2 < NG; ++g2) sum += red[(g2 * LPS + li) * NCH + c];
-                v.part_sinj_w[(size_t)blockIdx.x * T + t] = sum;
+                v.part_sinj_w[(size_t)blk * T + t] = sum;
             }
         }
     }
@@ -1112,7 +1132,37 @@ __global__ __launch_bounds__(256) void k_sto_warm(DevView v)
         if (tid < sft) redc[tid] += redc[tid + sft];
         __syncthreads();
     }
-    if (tid == 0) { v.part_scost_w[blockIdx.x] = redc[0]; v.item_fail[blockIdx.x] = blockFail; }
+    if (tid == 0) { v.part_scost_w[blk] = redc[0]; v.item_fail[blk] = blockFail; }
+    return blockFail;
+}
+
+template <int LPS, int NCH, bool LINES>
+__global__ __launch_bounds__(256) void k_sto_warm(DevView v)
+{
+    if (v.st->halt) return;
+    sto_warm_body<LPS, NCH, LINES>(v, blockIdx.x);
+}
+
+// All x-updates of one copper-plate iteration in ONE launch: blocks [0, nStoItems) solve storages (warm start,
+// then the scan for what it left over, in the same block), the rest sweep generators. The storage blocks are
+// latency/VALU work, the generator blocks are pure streaming, so sharing the CUs hides one behind the other
+// and two kernel boundaries (~4 us each of fixed cost) disappear. Storage blocks come first: they are the long
+// ones (interleaving the two kinds in dispatch order starts the last storage blocks late and costs 50 %).
+// The launch runs at the storage code's 3 waves/SIMD, which starves the streaming generator blocks once the
+// grid is large, so dopf_create only fuses grids whose storage blocks are all resident from the start.
+template <int LPS, int NCH, bool SKIP>
+__global__ __launch_bounds__(256) void k_agents(DevView v)
+{
+    if (v.st->halt) return;
+    const int nS = v.nStoItems;
+    if ((int)blockIdx.x < nS) {
+        const int left = sto_warm_body<LPS, NCH, false>(v, blockIdx.x);     // ends on a __syncthreads: its sto_fail
+        sto_cold_body<LPS, NCH, false>(v, blockIdx.x, left);                // flags are visible to the block here
+    } else if (SKIP) {
+        gen_pair_skip_body<256>(v, blockIdx.x - nS);
+    } else {
+        gen_pair_body<256>(v, blockIdx.x - nS);
+    }
 }
 
 bool sto_config_supported(int T, Launch *lc)
@@ -1136,6 +1186,24 @@ static void launch_sto_t(const DevView &v, hipStream_t s)
     }
     if (v.L > 0) hipLaunchKernelGGL((k_sto_update<LPS, NCH, true>), dim3(v.nStoItems), dim3(256), 0, s, v);
     else hipLaunchKernelGGL((k_sto_update<LPS, NCH, false>), dim3(v.nStoItems), dim3(256), 0, s, v);
+}
+
+template <int LPS, int NCH>
+static void launch_agents_t(const DevView &v, hipStream_t s)
+{
+    const dim3 grid(v.nStoItems + v.nGenItems);
+    if (v.genSkip) hipLaunchKernelGGL((k_agents<LPS, NCH, true>), grid, dim3(256), 0, s, v);
+    else hipLaunchKernelGGL((k_agents<LPS, NCH, false>), grid, dim3(256), 0, s, v);
+}
+
+void launch_agents_fused(const DevView &v, const Launch &lc, hipStream_t s)
+{
+#define DOPF_CASE(LPS_, NCH_) if (lc.stoLPS == LPS_ && lc.stoNCH == NCH_) { launch_agents_t<LPS_, NCH_>(v, s); return; }
+    DOPF_CASE(8, 1) DOPF_CASE(8, 2) DOPF_CASE(8, 3)
+    DOPF_CASE(16, 3)
+    DOPF_CASE(32, 3)
+    DOPF_CASE(64, 3)
+#undef DOPF_CASE
 }
 
 void launch_sto_update(const DevView &v, const Launch &lc, hipStream_t s)

@@ -101,6 +101,8 @@ typedef struct dopf_params {
 
 #define DOPF_F_NO_ROW_SKIP   8  /* generators: always sweep every row of P (no skipping of saturated rows)    */
 #define DOPF_F_NO_WARM_START 4  /* storages: always the cold price-threshold scan (no warm-start kernel) */
+#define DOPF_F_NO_FUSE      16  /* copper plate: generator and storage x-updates as separate launches instead
+                                   of the single k_agents launch                                           */
 
 /* Fill q with the reference's defaults (values above). */
 void dopf_default_params(dopf_params *q);
@@ -155,10 +157,13 @@ int dopf_set_state(dopf_ctx *ctx, const double *P, const double *D, const double
 /* Measurement: n_iters iterations launched kernel by kernel (no graph) with a hipEvent pair around
  * every kernel on the stream it runs on; one host sync at the end. Average milliseconds per launch. */
 typedef struct dopf_timing {
-    double tables_ms, gen_ms, sto_ms, slack_ms, reduce_ms, dual_ms;  /* per-kernel averages     */
+    double tables_ms, gen_ms, sto_ms, slack_ms, reduce_ms, dual_ms;  /* per-kernel averages; with agents_fused
+                                                                        gen_ms is the ONE x-update launch
+                                                                        (k_agents) and sto_ms an empty pair */
     double iter_ms;                                                  /* whole iteration, event to event */
     double empty_ms;    /* an event pair with nothing between: the fixed cost inside every number above */
     int32_t iters;
+    int32_t agents_fused;   /* 1: generators and storages ran as one launch */
 } dopf_timing;
 int dopf_iterate_timed(dopf_ctx *ctx, int32_t n_iters, dopf_timing *out);
 

@@ -162,14 +162,16 @@ def test_hip_rejects_bad_input(hip_api):
 def test_hip_is_bitwise_reproducible(hip_api):
     """Fixed-order reductions: two runs give identical bits, with and without the graph."""
     pp = synth.synthetic_case(3000, 300, 24, seed=31)
-    outs = []
-    for flags in (0, 0, _capi.F_NO_GRAPH, _capi.F_OVERLAP_AGENTS):
-        e = make_engine(hip_api, pp, eps=0.0, gamma=1.0 / 3300, flags=flags)
-        e.iterate(40)
-        outs.append(state_of(e))
-    for o in outs[1:]:
-        for k in outs[0]:
-            assert np.array_equal(outs[0][k], o[k]), k
+    # (the fused and the separate launches group their partial sums differently: two families)
+    for family in ((0, 0, _capi.F_NO_GRAPH), (_capi.F_NO_FUSE, _capi.F_NO_FUSE, _capi.F_OVERLAP_AGENTS)):
+        outs = []
+        for flags in family:
+            e = make_engine(hip_api, pp, eps=0.0, gamma=1.0 / 3300, flags=flags)
+            e.iterate(40)
+            outs.append(state_of(e))
+        for o in outs[1:]:
+            for k in outs[0]:
+                assert np.array_equal(outs[0][k], o[k]), (family, k)
 
 
 def test_hip_sharded_contexts_equal_one(hip_api):
@@ -241,6 +243,26 @@ def test_hip_full_size_properties(hip_api, name, idx, scale):
     cost = float(pp.gen_mc @ after["P"].sum(axis=1) + pp.sto_mc @ (D + C).sum(axis=1))
     assert abs(after["cost"][0] - cost) <= 1e-10 * cost
     assert e.solver_failures() == 0
+
+
+@pytest.mark.parametrize("case", ["config1", "config2/5", "config4/5", "340k+2k x24 (fused and row skipping)"])
+def test_hip_fused_agents_match_separate_launches(hip_api, case):
+    """k_agents (one launch for generators + storages) against the separate kernels: same iterates up to the
+    rounding of differently grouped partial sums."""
+    pp = {"config1": lambda: synth.baseline_config(1), "config2/5": lambda: synth.baseline_config(2, scale=0.2),
+          "config4/5": lambda: synth.baseline_config(4, scale=0.2)}.get(case, lambda: synth.synthetic_case(340000, 2000, 24))()
+    g = 1.0 / (pp.G + pp.S)
+    a = make_engine(hip_api, pp, eps=0.0, gamma=g)
+    b = make_engine(hip_api, pp, eps=0.0, gamma=g, flags=_capi.F_NO_FUSE)
+    assert a.iterate_timed(1)["agents_fused"] == 1 and b.iterate_timed(1)["agents_fused"] == 0
+    for n in (1, 5, 40, 150):
+        a.iterate(n)
+        b.iterate(n)
+        for x, y in zip(a.get_primal(), b.get_primal()):
+            assert np.abs(x - y).max() <= 1e-9 * (1.0 + np.abs(y).max())
+        la, lb = a.get_duals()[0], b.get_duals()[0]
+        assert np.abs(la - lb).max() <= 1e-10 * (1.0 + np.abs(lb).max())
+    assert a.solver_failures() == 0 and b.solver_failures() == 0
 
 
 def test_hip_row_skipping_is_bit_identical(hip_api):
