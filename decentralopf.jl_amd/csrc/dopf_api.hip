@@ -268,6 +268,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         int chunk = std::max(R, (G + 2047) / 2048);
         chunk = (chunk + R - 1) / R * R;
         make_items(gnode, N, chunk, gitems, ngb, ngib);
+        // (on short blocks the skip test costs more than the rows it saves: measured on config1/config2)
         v.genSkip = (v.genTT2 > 0 && chunk >= 8 * R && !(q->flags & DOPF_F_NO_ROW_SKIP)) ? 1 : 0;
         const int NG = S > 0 ? 256 / lc.stoLPS : 1;
         int schunk = std::max(NG, (S + 2047) / 2048);

@@ -813,6 +813,26 @@ __device__ __forceinline__ void seg_scan2(int &f, double &a, double &b, int lane
 #undef DOPF_SEG_STEP
 }
 
+// same, with (max, min) instead of (+, +): a <- max over the segment so far, b <- min
+template <int LPS>
+__device__ __forceinline__ void seg_scan_maxmin(int &f, double &a, double &b, int lane)
+{
+    const int r = lane & ((LPS < 16 ? LPS : 16) - 1);
+#define DOPF_SEG_STEP(CTRL, RM, COND)                                                        \
+    {                                                                                        \
+        const int pf = __builtin_amdgcn_update_dpp(f, f, CTRL, RM, 0xF, false);              \
+        const double pa = dppd<CTRL, RM>(a, a), pb = dppd<CTRL, RM>(b, b);                   \
+        if (COND) { if (!f) { a = fmax(a, pa); b = fmin(b, pb); } f |= pf; }                 \
+    }
+    DOPF_SEG_STEP(0x111, 0xF, r >= 1)
+    if (LPS >= 4) DOPF_SEG_STEP(0x112, 0xF, r >= 2)
+    if (LPS >= 8) DOPF_SEG_STEP(0x114, 0xF, r >= 4)
+    if (LPS >= 16) DOPF_SEG_STEP(0x118, 0xF, r >= 8)
+    if (LPS >= 32) DOPF_SEG_STEP(0x142, 0xA, lane & 16)
+    if (LPS >= 64) DOPF_SEG_STEP(0x143, 0xC, lane & 32)
+#undef DOPF_SEG_STEP
+}
+
 template <int LPS>
 __device__ __forceinline__ double group_max(double x)
 {
@@ -955,10 +975,10 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
         for (int c = 0; c < NCH; ++c) nuv[c] = (tbase + c < T) ? nuL[send[c]] : 0.0;
 
         // ---- segmented Newton ---------------------------------------------------------------------
-        double Dv[NCH], Cv[NCH], px[NCH];
+        double Dv[NCH], Cv[NCH], px[NCH], ps[NCH];
         bool conv = false;
         for (int itn = 0; itn < 8; ++itn) {
-            double sg[NCH], ps[NCH];
+            double sg[NCH];
             int f = 0;
             double rx = 0.0, rs = 0.0;
             bool seen[NCH];
@@ -1031,8 +1051,50 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
 #ifdef DOPF_STATS
         bool okLevel = true;
 #endif
+        // Copper plate: a segment whose steps ALL sit on a corner of their (D, C) box (charging or discharging at
+        // full rate, or idle) does not move with its price: every price in the intersection of the steps' corner
+        // intervals is a multiplier of that segment, not just the one Newton happened to stop at. With
+        // grad_D = a D - gam C - (rD0 - nu), grad_C = a C - gam D - (rC0 + nu):
+        //   D = 0: nu >= rD0 + gam C      D = pm: nu <= rD0 - a pm + gam C
+        //   C = 0: nu <= -rC0 - gam D     C = pm: nu >= a pm - gam D - rC0
+        double slo[NCH], shi[NCH];
+        if (!LINES) {
+            int f = 0;
+            double rl = -INFINITY, rh = INFINITY;
+            bool seen[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int t = tbase + c;
+                double lo = -INFINITY, hi = INFINITY;
+                if (t < T) {
+                    const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
+                    const double rD0 = w * D0[c] - mc - theta, rC0 = w * C0[c] - mc + theta;
+                    const double dd = Dv[c], cc = Cv[c];
+                    if (dd <= 0.0) lo = rD0 + gam * cc; else if (dd >= pm) hi = rD0 - a0 * pm + gam * cc;
+                    if (cc <= 0.0) hi = fmin(hi, -rC0 - gam * dd); else if (cc >= pm) lo = fmax(lo, a0 * pm - gam * dd - rC0);
+                }
+                if (st[c]) { rl = -INFINITY; rh = INFINITY; f = 1; }
+                rl = fmax(rl, lo); rh = fmin(rh, hi);
+                slo[c] = rl; shi[c] = rh;
+                seen[c] = f != 0;
+            }
+            int fl = f;
+            double al = rl, ah = rh;
+            seg_scan_maxmin<LPS>(fl, al, ah, lane);
+            double cl = prev_lane<LPS>(al), ch = prev_lane<LPS>(ah);
+            if (li == 0) { cl = -INFINITY; ch = INFINITY; }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+                if (!seen[c]) { slo[c] = fmax(slo[c], cl); shi[c] = fmin(shi[c], ch); }
+        }
         double Ev[NCH], mlo[NCH], mhi[NCH];
-        double alo = -INFINITY, ahi = INFINITY;              // this lane's maps, composed right to left
+        // Prices: segment i (ending at contact e_i) may take any nu_i in [mlo, mhi] (a point unless the segment is
+        // flat); an empty contact needs nu_i >= nu_{i+1}, a full one nu_i <= nu_{i+1}, and nu past the horizon is 0.
+        // Right to left, the set of nu_i that can be completed to the right is the interval
+        //   empty: [max(mlo, flo_{i+1}), mhi]      full: [mlo, min(mhi, fhi_{i+1})]      open last segment: {0}
+        // — two chains of clamp maps (one for the lower ends, one for the upper ends), one suffix scan each;
+        // the certificate holds iff no interval is empty.
+        double alo = -INFINITY, ahi = INFINITY, blo = -INFINITY, bhi = INFINITY;      // this lane's composed maps
 #pragma unroll
         for (int c = NCH - 1; c >= 0; --c) {
             const int t = tbase + c;
@@ -1048,32 +1110,43 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
                 }
                 if (isend[c]) {
                     mlo[c] = mhi[c] = kind[c] != 0 ? nuv[c] : 0.0;
-                    if (kind[c] != 0 && st[c] && base[t] == tgt[c]) {
-                        // with D = C = 0 the step's net injection is unchanged at q = 0: dlt = -q0
+                    if (!LINES) {
+                        // flat segment (zero slope at its end = every step on a corner): the whole interval
+                        if (kind[c] != 0 && ps[c] == 0.0 && slo[c] <= shi[c] && nuv[c] >= slo[c] - 1e-9 && nuv[c] <= shi[c] + 1e-9) {
+                            mlo[c] = slo[c]; mhi[c] = shi[c];
+                        }
+                    } else if (kind[c] != 0 && st[c] && base[t] == tgt[c]) {
+                        // idle on a bound: with D = C = 0 the step's net injection is unchanged at q = 0: dlt = -q0
                         const double q0 = D0[c] - C0[c];
-                        const double theta = LINES ? tab_psi_at(tab_ref(v, it.node, t), -q0) : th0[c] - gam * q0;
+                        const double theta = tab_psi_at(tab_ref(v, it.node, t), -q0);
                         const double rD0 = w * D0[c] - mc - theta, rC0 = w * C0[c] - mc + theta;
                         if (rD0 <= -rC0 && nuv[c] >= rD0 - 1e-9 && nuv[c] <= -rC0 + 1e-9) { mlo[c] = rD0; mhi[c] = -rC0; }
                     }
+                    // lower-end chain: empty x -> max(mlo, x), full/open x -> mlo; upper-end chain: empty/open x -> mhi, full x -> min(mhi, x)
+                    const double a_lo = mlo[c], a_hi = kind[c] == 1 ? INFINITY : mlo[c];
+                    const double b_lo = kind[c] == 2 ? -INFINITY : mhi[c], b_hi = mhi[c];
+                    const double nal = clampd(alo, a_lo, a_hi), nah = clampd(ahi, a_lo, a_hi);
+                    const double nbl = clampd(blo, b_lo, b_hi), nbh = clampd(bhi, b_lo, b_hi);
+                    alo = nal; ahi = nah; blo = nbl; bhi = nbh;
                 }
             }
-            const double nlo = clampd(alo, mlo[c], mhi[c]), nhi = clampd(ahi, mlo[c], mhi[c]);   // M_c o (maps to the right)
-            alo = nlo; ahi = nhi;
         }
         scan_clamps_rev<LPS>(alo, ahi, lane);
-        // price arriving from the right of this lane: (lanes to the right)(0)
-        const double rightv = next_lane<LPS>(clampd(0.0, alo, ahi));
-        double val = li == LPS - 1 ? 0.0 : rightv;
+        scan_clamps_rev<LPS>(blo, bhi, lane);
+        // ends of the feasible interval arriving from the right of this lane: (lanes to the right)(0)
+        const double rightA = next_lane<LPS>(clampd(0.0, alo, ahi)), rightB = next_lane<LPS>(clampd(0.0, blo, bhi));
+        double flo = li == LPS - 1 ? 0.0 : rightA, fhi = li == LPS - 1 ? 0.0 : rightB;
 #pragma unroll
         for (int c = NCH - 1; c >= 0; --c) {
             const int t = tbase + c;
-            const double vin = val;
-            val = clampd(val, mlo[c], mhi[c]);
-            if (t < T && isend[c] && kind[c] != 0) {
-                const double tn = 1e-10 * (1.0 + fabs(val));
-                if (kind[c] == 1 && vin > val + tn) okk = false;      // empty: price may only fall going forward
-                if (kind[c] == 2 && vin < val - tn) okk = false;      // full: price may only rise
-                nuv[c] = val;                                          // (moves only inside a dead band)
+            if (t < T && isend[c]) {
+                flo = kind[c] == 1 ? fmax(mlo[c], flo) : mlo[c];
+                fhi = kind[c] == 2 ? fmin(mhi[c], fhi) : mhi[c];
+                if (kind[c] != 0) {
+                    const double tn = 1e-10 * (1.0 + fmin(fabs(flo), fabs(fhi)));
+                    if (flo > fhi + tn) okk = false;
+                    nuv[c] = clampd(nuv[c], flo, fmax(flo, fhi));      // (moves only inside a flat segment's interval)
+                }
             }
         }
 #ifdef DOPF_STATS
