@@ -104,9 +104,17 @@ void make_items(const std::vector<int> &node_sorted, int N, int chunk, std::vect
     node_item_beg[N] = (int)items.size();
 }
 
-void enqueue_local(dopf_ctx *c)
+// single: the single-GPU dopf_iterate path (nothing reads cons between the reduce and the dual step)
+static bool slice_dual(const DevView &v, bool single)
 {
-    const DevView &v = c->v;
+    const size_t NT = (size_t)v.N * v.T, LT = (size_t)v.L * v.T;
+    return single && std::max(NT, LT) <= kSmallConsensus && NT <= 256;     // k_dual_price_small: 8 chunks of 32 entries
+}
+
+void enqueue_local(dopf_ctx *c, bool single)
+{
+    DevView v = c->v;
+    v.sliceDual = slice_dual(v, single) ? 1 : 0;
     launch_tables(v, c->main);
     const bool fork = v.nGenItems > 0 && v.nStoItems > 0 && (c->q.flags & DOPF_F_OVERLAP_AGENTS);
     if (v.fuseAgents) {
@@ -126,7 +134,12 @@ void enqueue_local(dopf_ctx *c)
     launch_reduce(v, c->main);
 }
 
-void enqueue_apply(dopf_ctx *c) { launch_dual(c->v, c->main); }
+void enqueue_apply(dopf_ctx *c, bool single)
+{
+    DevView v = c->v;
+    v.sliceDual = slice_dual(v, single) ? 1 : 0;
+    launch_dual(v, c->main);
+}
 
 void drop_graphs(dopf_ctx *c)
 {
@@ -140,7 +153,7 @@ int build_graph(dopf_ctx *c, int iters, hipGraphExec_t *out)
 {
     hipGraph_t g = nullptr;
     HIPCHK(c, hipStreamBeginCapture(c->main, hipStreamCaptureModeRelaxed));
-    for (int i = 0; i < iters; ++i) { enqueue_local(c); enqueue_apply(c); }
+    for (int i = 0; i < iters; ++i) { enqueue_local(c, true); enqueue_apply(c, true); }
     HIPCHK(c, hipStreamEndCapture(c->main, &g));
     hipError_t e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
     hipGraphDestroy(g);
@@ -280,7 +293,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     {
         // level-1 reduce blocks per node: ~16 items per block, at most 64 (and N*RB blocks in total)
         int max_items = 1;
-        for (int n = 0; n < N; ++n) max_items = std::max(max_items, (ngib[n + 1] - ngib[n]) + (nsib[n + 1] - nsib[n]));
+        for (int n = 0; n < N; ++n) max_items = std::max(max_items, (ngib[n + 1] - ngib[n]) + 2 * (nsib[n + 1] - nsib[n]));   // storage items: scan + warm rows
         v.reduceRB = std::max(1, std::min(64, (max_items + 31) / 32));
     }
 
@@ -368,7 +381,7 @@ int dopf_iterate(dopf_ctx *c, int32_t n_iters, int32_t *iters_done, int32_t *con
         int slice = std::min(left, kCheckEvery);
         left -= slice;
         if (eager) {
-            for (int i = 0; i < slice; ++i) { enqueue_local(c); enqueue_apply(c); }
+            for (int i = 0; i < slice; ++i) { enqueue_local(c, true); enqueue_apply(c, true); }
         } else {
             for (; slice >= kUnroll; slice -= kUnroll) HIPCHK(c, hipGraphLaunch(c->graphU, c->main));
             for (; slice > 0; --slice) HIPCHK(c, hipGraphLaunch(c->graph1, c->main));
@@ -388,7 +401,8 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
 {
     if (!c || !out || n_iters < 1 || n_iters > 4096) return fail(c, DOPF_E_INVALID, "bad argument");
     DeviceGuard guard(c->device);
-    const DevView &v = c->v;
+    DevView v = c->v;
+    v.sliceDual = slice_dual(v, true) ? 1 : 0;
     enum { E_T0, E_T1, E_G0, E_G1, E_S0, E_S1, E_K0, E_K1, E_R1, E_D1, E_X0, E_X1, E_N };
     std::vector<hipEvent_t> ev((size_t)n_iters * E_N);
     for (auto &e : ev) HIPCHK(c, hipEventCreate(&e));
@@ -448,7 +462,7 @@ int dopf_local_update(dopf_ctx *c)
 {
     if (!c) return DOPF_E_INVALID;
     DeviceGuard guard(c->device);
-    enqueue_local(c);
+    enqueue_local(c, false);
     HIPCHK(c, hipGetLastError());
     return DOPF_OK;
 }
@@ -457,7 +471,7 @@ int dopf_apply_consensus(dopf_ctx *c)
 {
     if (!c) return DOPF_E_INVALID;
     DeviceGuard guard(c->device);
-    enqueue_apply(c);
+    enqueue_apply(c, false);
     HIPCHK(c, hipGetLastError());
     return DOPF_OK;
 }

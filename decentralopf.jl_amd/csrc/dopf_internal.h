@@ -46,6 +46,8 @@ struct DevView {
     int genTT, genR;                // generator block tiling: TT = min(T, 512) timesteps x R agents
     int genSkip;                    // pair kernel with row skipping (blocks sweep >= 8 passes of agents)
     int genTT2, genR2;              // pair kernel (copper plate, even T <= 1024): T/2 double2 columns x R2 agents; 0 = off
+    int sliceDual;                  // per launch: k_reduce stops after the slice sums (level 1) and the one-block dual
+                                    // kernel adds the slices itself (single-GPU iterate path, small consensus state)
     int reduceRB;                   // reduce blocks per node (two-level fixed-order sum)
     int fuseAgents;                 // copper plate, even T: generators + storages in one launch (k_agents, 256-thread blocks)
     int use_warm;                   // storage warm-start kernel runs first; the scan kernel serves its failures
@@ -79,6 +81,9 @@ struct DevView {
     double *cons;
     Status *st;
 };
+
+// consensus states up to this many (n,t) / (l,t) entries take the one-block dual step
+constexpr size_t kSmallConsensus = 4096;
 
 struct Launch {
     int stoLPS, stoNCH;

@@ -222,25 +222,27 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
         const int r = tid >> 5, tt = tid & 31, t = tcx * TT + tt;
         const int g0 = v.node_gitem_beg[n], ngi = v.node_gitem_beg[n + 1] - g0;
         const int s0 = v.node_sitem_beg[n], nsi = v.node_sitem_beg[n + 1] - s0;
-        const int ni = ngi + nsi;                       // generator items first, then storage items
+        // rows to add: generator items, then the storage items' scan partials, then their warm-start partials
+        const int ni = ngi + 2 * nsi;
         const int per = (ni + RB - 1) / RB;
         const int i0 = rb * per, i1 = min(ni, i0 + per);
         double acc = 0.0;
         if (t < T) {
-            // two independent chains keep several loads in flight; the grouping is fixed, so is the result
-            double a0 = 0.0, a1 = 0.0;
-            int i = i0 + r;
-            for (; i + R < i1; i += 2 * R) {
-                const int j = i + R;
-                a0 += i < ngi ? v.part_ginj[(size_t)(g0 + i) * T + t]
-                              : v.part_sinj[(size_t)(s0 + i - ngi) * T + t] + v.part_sinj_w[(size_t)(s0 + i - ngi) * T + t];
-                a1 += j < ngi ? v.part_ginj[(size_t)(g0 + j) * T + t]
-                              : v.part_sinj[(size_t)(s0 + j - ngi) * T + t] + v.part_sinj_w[(size_t)(s0 + j - ngi) * T + t];
+            // four loads in flight per lane, no branch between them (one select on the address); fixed grouping
+            for (int i = i0 + r; i < i1; i += 4 * R) {
+                double x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = i + u * R;
+                    const int jj = j < i1 ? j : i0;                               // in range: always a valid row
+                    const double *row = jj < ngi ? v.part_ginj + (size_t)(g0 + jj) * T
+                                      : (jj < ngi + nsi ? v.part_sinj + (size_t)(s0 + jj - ngi) * T
+                                                        : v.part_sinj_w + (size_t)(s0 + jj - ngi - nsi) * T);
+                    const double val = row[t];
+                    x[u] = j < i1 ? val : 0.0;
+                }
+                acc += (x[0] + x[1]) + (x[2] + x[3]);
             }
-            if (i < i1)
-                a0 += i < ngi ? v.part_ginj[(size_t)(g0 + i) * T + t]
-                              : v.part_sinj[(size_t)(s0 + i - ngi) * T + t] + v.part_sinj_w[(size_t)(s0 + i - ngi) * T + t];
-            acc = a0 + a1;
         }
         red[tid] = acc;
         __syncthreads();
@@ -259,6 +261,7 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
             c = block_sum256(c, red);
             if (tid == 0) v.part2_cost[rb] = c;
         }
+        if (v.sliceDual) return;        // the dual kernel adds the slices (and the cost slices) itself
         // publish, take a ticket; the last block of this (node, timestep chunk) finishes the sum.
         // Hand-off per cdna_hip_programming.md G16: every storing wave drains its stores, the block meets,
         // ONE lane releases at agent scope and takes the ticket; the last block's lane acquires, the block
@@ -279,8 +282,16 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
         if (last_sh) {
             // 8 lanes per timestep take interleaved slices; combined in a fixed order
             double sum = 0.0;
-            if (t < T)
-                for (int q = r; q < RB; q += R) sum += v.part2[((size_t)n * RB + q) * T + t];
+            if (t < T) {
+                double x[8];                              // RB <= 64: all of this lane's slices in flight at once
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int q = r + R * k;
+                    x[k] = q < RB ? v.part2[((size_t)n * RB + q) * T + t] : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sum += x[k];
+            }
             __syncthreads();
             red[tid] = sum;
             __syncthreads();
@@ -289,10 +300,10 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
                 for (int q = 0; q < R; ++q) tot += red[q * TT + tt];
                 v.cons[n + (size_t)N * t] = tot;
             }
-            if (n == 0 && tcx == 0 && tid == 0) {
-                double c = 0.0;
-                for (int q = 0; q < RB; ++q) c += v.part2_cost[q];
-                v.cons[(size_t)N * T + 2 * (size_t)L * T] = c;
+            if (n == 0 && tcx == 0 && tid < 64) {          // cost slices: side by side in wave 0, butterfly sum
+                double c = tid < RB ? v.part2_cost[tid] : 0.0;
+                for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+                if (tid == 0) v.cons[(size_t)N * T + 2 * (size_t)L * T] = c;
             }
             if (tid == 0) v.reduce_ticket[n * TC + tcx] = 0;       // ready for the next iteration
         }
@@ -438,10 +449,58 @@ template <bool UPDATE>
 __global__ __launch_bounds__(256) void k_dual_price_small(DevView v)
 {
     if (UPDATE && v.st->halt) return;
-    __shared__ double red[3][256];
+    __shared__ double red[8][256];
     const int tid = threadIdx.x;
     const size_t NT = (size_t)v.N * v.T, LT = (size_t)v.L * v.T;
     const size_t n1 = NT > LT ? NT : LT;
+    if (UPDATE && v.sliceDual) {
+        // level 2 of the consensus sum, here instead of behind a ticket in k_reduce: slice order, so the bits are
+        // the ones the two-level kernel produces
+        const int RB = v.reduceRB, N = v.N, T = v.T, R = 8;
+        const int r = tid >> 5, tt = tid & 31;            // 8 slice lanes x 32 entries, as in k_reduce
+        // N*T <= 256 here (slice_dual() in dopf_api.hip): up to 8 chunks of 32 entries, every load of every chunk
+        // issued before the first use, ONE barrier
+        double sc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const size_t i = (size_t)c * 32 + tt;
+            sc[c] = 0.0;
+            if (i < NT) {
+                const int n = (int)(i % N), t = (int)(i / N);
+                double x[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int q = r + R * k;
+                    x[k] = q < RB ? v.part2[((size_t)n * RB + q) * T + t] : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sc[c] += x[k];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) red[c][tid] = sc[c];
+        __syncthreads();
+        if (r == 0) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const size_t i = (size_t)c * 32 + tt;
+                if (i < NT) {
+                    double tot = 0.0;
+                    for (int q = 0; q < R; ++q) tot += red[c][q * 32 + tt];
+                    v.cons[i] = tot;
+                }
+            }
+        }
+        __syncthreads();
+        // cost slices: loaded side by side (one lane adding them from memory is a chain of RB dependent loads —
+        // 8 us for 64 slices)
+        if (tid < 64) {                                   // wave 0: a butterfly is a fixed order too
+            double c = tid < RB ? v.part2_cost[tid] : 0.0;
+            for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+            if (tid == 0) v.cons[NT + 2 * LT] = c;
+        }
+        __syncthreads();
+    }
     double rl = 0.0, rm = 0.0, rr = 0.0;
     for (size_t i = tid; i < n1; i += 256) dual_body<UPDATE>(v, i, rl, rm, rr);
     if (UPDATE) {
@@ -462,8 +521,6 @@ __global__ __launch_bounds__(256) void k_dual_price_small(DevView v)
         if (tid == 0) status_update(v, red[0][0], red[1][0], red[2][0]);
     }
 }
-
-constexpr size_t kSmallConsensus = 4096;
 
 void launch_dual(const DevView &v, hipStream_t s)
 {
