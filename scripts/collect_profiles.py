@@ -14,6 +14,8 @@ for w in workloads:
     d = f"gpurun_out/prof_{w}"
     s = json.load(open(f"{d}/summary.json"))
     shutil.copy(f"{d}/kernel_stats.csv", f"profiles/{tag}_{w}_kernel_stats.csv")
+    if os.path.exists(f"{d}/kernel_stats_windows.csv"):
+        shutil.copy(f"{d}/kernel_stats_windows.csv", f"profiles/{tag}_{w}_kernel_stats_windows.csv")
     pmc[w] = {k.split("::")[-1]: {"FETCH_SIZE": v.get("FETCH_SIZE", {}).get("mean"), "WRITE_SIZE": v.get("WRITE_SIZE", {}).get("mean"),
                                   "launches_averaged": v.get("FETCH_SIZE", v.get("WRITE_SIZE", {})).get("n")}
               for k, v in s["pmc"].items() if "dopf::" in k}

@@ -1,5 +1,6 @@
 #!/bin/bash
-# rocprofv3 profile of bench.py for one workload; summaries land in gpurun_out/prof_<workload>/ and are
+# rocprofv3 profile of bench.py for one workload (kernel_stats.csv = ALL launches of the process, kernel_stats_windows.csv =
+# the launches bench.py's events time); summaries land in gpurun_out/prof_<workload>/ and are
 # copied into profiles/ by hand (profiles/ is tracked, gpurun_out/ is scratch).
 #   pass 1: --kernel-trace --stats          per-kernel durations (must agree with bench.py's HIP-event numbers)
 #   pass 2: --pmc FETCH_SIZE                HBM read traffic   } separate passes, no tracing mixed in
@@ -22,6 +23,25 @@ for f in glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
     out["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs") if k in r} for r in rows]
     import shutil; shutil.copy(f, "$OUT/kernel_stats.csv")
+# the same windows bench.py's events cover, from the kernel trace: launch order is engine 1 = W+K graph iterations,
+# engine 2 (replay) = W graph iterations + K event-timed ones, of which the last `timed_iters` are the steady state
+line = json.loads(open("$OUT/trace.json").read().strip().splitlines()[-1])
+W, K, tail = line["warmup"], line["steps"], 32
+for f in glob.glob("$OUT/trace/**/*kernel_trace.csv", recursive=True):
+    rows = sorted((r for r in csv.DictReader(open(f)) if "dopf::" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+    by = collections.defaultdict(list)
+    for r in rows:
+        by[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    win = []
+    for k, d in by.items():
+        if len(d) < 2 * (W + K):
+            continue
+        reg, st = d[2 * W + K: 2 * W + 2 * K], d[2 * W + 2 * K - tail: 2 * W + 2 * K]
+        win.append({"Name": k, "window": "timed-region replay", "Calls": len(reg), "AverageNs": sum(reg) / len(reg), "MinNs": min(reg), "MaxNs": max(reg)})
+        win.append({"Name": k, "window": "steady state (last %d)" % tail, "Calls": len(st), "AverageNs": sum(st) / len(st), "MinNs": min(st), "MaxNs": max(st)})
+    out["kernel_stats_windows"] = win
+    with open("$OUT/kernel_stats_windows.csv", "w", newline="") as fh:
+        wr = csv.DictWriter(fh, fieldnames=["Name", "window", "Calls", "AverageNs", "MinNs", "MaxNs"]); wr.writeheader(); wr.writerows(win)
 pmc = {}
 for name in ("fetch", "write"):
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % name, recursive=True):
