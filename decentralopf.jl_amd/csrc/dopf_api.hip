@@ -206,7 +206,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     Launch lc{};
     if (p->S > 0 && !sto_config_supported(p->T, &lc))
         return fail(nullptr, DOPF_E_UNSUPPORTED, "storage kernel supports T <= 512 (got %d)", p->T);
-    if (2 * p->L > 4096) return fail(nullptr, DOPF_E_UNSUPPORTED, "table kernel supports L <= 2048 (got %d)", p->L);
+    if (2 * p->L > 4096) return fail(nullptr, DOPF_E_UNSUPPORTED, "table kernel supports L <= 2048 (got %d)", p->L);   // 4 * 2L doubles of LDS
 
     int ndev = 0;
     hipError_t e0 = hipGetDeviceCount(&ndev);
@@ -305,6 +305,14 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     TRY(dev_upload(c, &v.sto_mc, smc)); TRY(dev_upload(c, &v.sto_pmax, spm)); TRY(dev_upload(c, &v.sto_emax, sem));
     TRY(dev_upload(c, &v.gen_items, gitems)); TRY(dev_upload(c, &v.sto_items, sitems));
     TRY(dev_upload(c, &v.node_gen_beg, ngb)); TRY(dev_upload(c, &v.node_sto_beg, nsb));
+    {
+        // a generator moves by at most pmax per iteration, a storage's net injection D - C by at most 2 pmax
+        std::vector<double> win(N, 0.0);
+        for (int i = 0; i < G; ++i) win[gnode[i]] = std::max(win[gnode[i]], gpm[i]);
+        for (int i = 0; i < S; ++i) win[snode[i]] = std::max(win[snode[i]], 2.0 * spm[i]);
+        for (int n = 0; n < N; ++n) win[n] = win[n] * (1.0 + 1e-9) + 1e-9;
+        TRY(dev_upload(c, &v.node_win, win));
+    }
     TRY(dev_upload(c, &v.node_gitem_beg, ngib)); TRY(dev_upload(c, &v.node_sitem_beg, nsib));
     TRY(dev_alloc(c, &v.P, (size_t)G * T));
     TRY(dev_alloc(c, &v.gen_state, G));            // zero = "all zero", which is what P is now

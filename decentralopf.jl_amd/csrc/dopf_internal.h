@@ -59,6 +59,7 @@ struct DevView {
     const double *sto_mc, *sto_pmax, *sto_emax;
     const Item *gen_items, *sto_items;
     const int *node_gen_beg, *node_sto_beg;         // N+1 each: agent ranges per node
+    const double *node_win;                         // N: bound on |change of an agent's net injection| at the node
     const int *node_gitem_beg, *node_sitem_beg;     // N+1 each: item ranges per node
     // primal state
     double *P, *D, *C, *E, *dltG, *dltS;

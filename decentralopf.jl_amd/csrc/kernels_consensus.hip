@@ -44,21 +44,39 @@ __device__ __forceinline__ double line_term(const DevView &v, int l, int t, doub
 }
 
 // ------------------------------------------------------------------------------------------------
-// breakpoint tables (L > 0): one block per (n,t)
+// breakpoint tables (L > 0): one wave per (n,t)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tables(DevView v, int P2)
+//
+// Psi_{n,t}(dlt) is piecewise linear with up to 2L kinks, but an agent at node n can only move its injection by
+// |dlt| <= W_n (a generator by pmax, a storage by 2 pmax): kinks left of -W_n only add their slope jumps to the
+// slope at the window's left end, kinks right of +W_n are never reached. Typically a handful of the 2L kinks lie
+// inside the window, so the table that the agent kernels search has a handful of entries, and building it is a
+// classification pass + a rank sort of the few survivors instead of a 512-key bitonic sort per (n,t).
+// Psi is anchored at dlt = 0 (direct evaluation) and walked outwards piece by piece, which keeps full precision
+// where the agents' steps live. Every sum has a fixed order (wave butterflies, list order).
+__device__ __forceinline__ double wave_sum64(double x)
+{
+    for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
+    return x;
+}
+
+__global__ __launch_bounds__(64) void k_tables(DevView v)
 {
     if (v.st->halt) return;
     extern __shared__ double shm[];
-    double *key = shm, *jmp = shm + P2, *red = shm + 2 * P2;     // red: 256 doubles
-    const int tid = threadIdx.x;
-    const size_t at = blockIdx.x;
     const int N = v.N, L = v.L, M2 = v.M2;
+    double *key = shm, *jmp = shm + M2, *skey = shm + 2 * M2, *sslope = shm + 3 * M2;   // sslope: M2 + 1
+    const int lane = threadIdx.x;
+    const size_t at = blockIdx.x;
     const int n = (int)(at % N), t = (int)(at / N);
     const double w2 = 2.0 * v.w_flow, g = v.gamma, act = g / (w2 + g);
+    const double W = v.node_win[n];
 
-    double s0part = 0.0;
-    for (int i = tid; i < P2; i += 256) {
+    // ---- classify the 2L candidate kinks; keep the ones inside [-W, W] in list order
+    double s0part = 0.0, left = 0.0, pz = 0.0;
+    int c = 0;
+    for (int base = 0; base < M2; base += 64) {
+        const int i = base + lane;
         double kv = INFINITY, jv = 0.0;
         if (i < M2) {
             const int l = i >> 1;
@@ -70,74 +88,68 @@ __global__ __launch_bounds__(256) void k_tables(DevView v, int P2)
                     kv = (g * v.avgU[l + L * t] / w2 - f + F) / h;
                     jv = h > 0.0 ? dj : -dj;
                     s0part += w2 * h * h * (1.0 + act);     // at -inf exactly one of U, K is active
+                    pz += line_term(v, l, t, h, 0.0);       // Psi(0), network part
                 } else {                     // K switches
                     kv = (-g * v.avgK[l + L * t] / w2 - f - F) / h;
                     jv = h > 0.0 ? -dj : dj;
                 }
             }
         }
-        key[i] = kv;
-        jmp[i] = jv;
-    }
-    __syncthreads();
-    // bitonic sort ascending on key, payload jmp
-    for (int k2 = 2; k2 <= P2; k2 <<= 1) {
-        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            for (int i = tid; i < P2; i += 256) {
-                const int ixj = i ^ j2;
-                if (ixj > i) {
-                    const bool up = (i & k2) == 0;
-                    const double a = key[i], b = key[ixj];
-                    if ((a > b) == up) {
-                        key[i] = b; key[ixj] = a;
-                        const double ja = jmp[i]; jmp[i] = jmp[ixj]; jmp[ixj] = ja;
-                    }
-                }
-            }
-            __syncthreads();
+        const bool fin = kv < INFINITY;                      // (also false for NaN)
+        if (fin && kv < -W) left += jv;
+        const bool in = fin && kv >= -W && kv <= W;
+        const unsigned long long mask = __ballot(in);
+        if (in) {
+            const int pos = c + __popcll(mask & ((1ull << lane) - 1ull));
+            key[pos] = kv;
+            jmp[pos] = jv;
         }
+        c += __popcll(mask);
     }
-    const double slope0 = g + block_sum256(s0part, red);
-    // number of finite kinks
-    __shared__ int m_sh;
-    if (tid == 0) m_sh = 0;
-    __syncthreads();
-    for (int i = tid; i < P2; i += 256)
-        if (key[i] < INFINITY && (i + 1 == P2 || !(key[i + 1] < INFINITY))) m_sh = i + 1;
-    __syncthreads();
-    const int m = m_sh;
-    // Psi(0) by direct evaluation; the kinks are then reached by walking the pieces outwards from 0.
-    // (Anchoring at 0 keeps full precision where the agents' steps live, |dlt| <= pmax, even when a
-    // numerically tiny PTDF entry throws a kink out to 1e19.)
-    double pz = 0.0;
-    for (int l = tid; l < L; l += 256) {
-        const double h = v.ptdf[l + L * n];
-        if (h != 0.0) pz += line_term(v, l, t, h, 0.0);
+    const double slope_left = g + wave_sum64(s0part) + wave_sum64(left);    // slope just right of -W
+    const double psiZ = v.price[n + N * t] + g * v.s[t] + wave_sum64(pz);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- rank sort (ties by list position), sorted keys and jumps into skey / sslope[1..]
+    for (int e = lane; e < c; e += 64) {
+        const double ke = key[e];
+        int r = 0;
+        for (int k = 0; k < c; ++k) {
+            const double kk = key[k];
+            r += (kk < ke || (kk == ke && k < e)) ? 1 : 0;
+        }
+        skey[r] = ke;
+        sslope[r + 1] = jmp[e];
     }
-    const double psiZ = v.price[n + N * t] + g * v.s[t] + block_sum256(pz, red);
+    __builtin_amdgcn_wave_barrier();
+    // ---- slopes: piece 0 = left of the first kept kink, piece j+1 = (kink j, kink j+1)
     double *ob = v.tb_beta + at * M2, *op = v.tb_psi + at * M2, *os = v.tb_slope + at * (M2 + 1);
-    if (tid == 0) {
-        double sl = slope0;
-        os[0] = sl;
-        int j0 = m;                                   // first kink >= 0
-        for (int j = 0; j < m; ++j) {
-            ob[j] = key[j];
-            if (j0 == m && key[j] >= 0.0) j0 = j;
-            sl += jmp[j];
-            os[j + 1] = sl;                           // slope on piece j+1 = (kink j, kink j+1)
+    int j0 = 0;                                              // number of kept kinks < 0: 0 lies on piece j0
+    for (int k = 0; k < c; ++k) j0 += skey[k] < 0.0 ? 1 : 0;
+    for (int j = lane; j < c; j += 64) {
+        double sl = slope_left;
+        for (int k = 0; k <= j; ++k) sl += sslope[k + 1];
+        key[j] = sl;                                         // (key[] is free now) slope on piece j+1
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- Psi at the kinks, outwards from 0
+    const double slope_j0 = j0 == 0 ? slope_left : key[j0 - 1];
+    for (int j = lane; j < c; j += 64) {
+        double ps;
+        if (j >= j0) {
+            ps = psiZ + slope_j0 * skey[j0];
+            for (int i = j0 + 1; i <= j; ++i) ps += key[i - 1] * (skey[i] - skey[i - 1]);       // slope on piece i = key[i-1]
+        } else {
+            ps = psiZ + slope_j0 * skey[j0 - 1];
+            for (int i = j0 - 2; i >= j; --i) ps -= key[i] * (skey[i + 1] - skey[i]);            // slope on piece i+1 = key[i]
         }
-        // 0 lies on piece j0
-        if (j0 < m) {
-            double ps = psiZ + os[j0] * key[j0];
-            op[j0] = ps;
-            for (int j = j0 + 1; j < m; ++j) { ps += os[j] * (key[j] - key[j - 1]); op[j] = ps; }
-        }
-        if (j0 > 0) {
-            double ps = psiZ + os[j0] * key[j0 - 1];
-            op[j0 - 1] = ps;
-            for (int j = j0 - 2; j >= 0; --j) { ps -= os[j + 1] * (key[j + 1] - key[j]); op[j] = ps; }
-        }
-        v.tb_m[at] = m;
+        ob[j] = skey[j];
+        op[j] = ps;
+        os[j + 1] = key[j];
+    }
+    if (lane == 0) {
+        os[0] = slope_left;
+        v.tb_m[at] = c;
         v.tb_psi0[at] = psiZ;
     }
 }
@@ -145,10 +157,13 @@ __global__ __launch_bounds__(256) void k_tables(DevView v, int P2)
 void launch_tables(const DevView &v, hipStream_t s)
 {
     if (v.L == 0) return;
-    int P2 = 2;
-    while (P2 < v.M2) P2 <<= 1;
-    const size_t shm = (size_t)(2 * P2 + 256) * sizeof(double);
-    hipLaunchKernelGGL(k_tables, dim3(v.N * v.T), dim3(256), shm, s, v, P2);
+    const size_t shm = (size_t)(4 * v.M2 + 1) * sizeof(double);
+    static bool big_lds = false;
+    if (shm > 64 * 1024 && !big_lds) {     // worst case (every kink inside the window) needs 4 * 2L doubles
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_tables), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        big_lds = true;
+    }
+    hipLaunchKernelGGL(k_tables, dim3(v.N * v.T), dim3(64), shm, s, v);
 }
 
 // ------------------------------------------------------------------------------------------------
