@@ -300,6 +300,12 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     const size_t NT = (size_t)N * T, LT = (size_t)L * T;
     TRY(dev_upload(c, &v.demand, std::vector<double>(p->demand, p->demand + NT)));
     TRY(dev_upload(c, &v.ptdf, std::vector<double>(p->ptdf, p->ptdf + (size_t)L * N)));
+    {
+        std::vector<double> pt((size_t)L * N);
+        for (int l = 0; l < L; ++l)
+            for (int n = 0; n < N; ++n) pt[n + (size_t)N * l] = p->ptdf[l + (size_t)L * n];
+        TRY(dev_upload(c, &v.ptdfT, pt));
+    }
     TRY(dev_upload(c, &v.fmax, std::vector<double>(p->f_max, p->f_max + L)));
     TRY(dev_upload(c, &v.gen_mc, gmc)); TRY(dev_upload(c, &v.gen_pmax, gpm));
     TRY(dev_upload(c, &v.sto_mc, smc)); TRY(dev_upload(c, &v.sto_pmax, spm)); TRY(dev_upload(c, &v.sto_emax, sem));

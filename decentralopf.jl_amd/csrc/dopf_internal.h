@@ -55,6 +55,7 @@ struct DevView {
     double gamma, w_flow, w_prox, eps, mask_thr, invA;
     // problem (read-only)
     const double *demand, *ptdf, *fmax;
+    const double *ptdfT;                            // [n + N*l]: the transpose, for the price kernel's node-major threads
     const double *gen_mc, *gen_pmax;
     const double *sto_mc, *sto_pmax, *sto_emax;
     const Item *gen_items, *sto_items;

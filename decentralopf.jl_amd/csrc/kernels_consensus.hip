@@ -11,6 +11,8 @@
 //              (src/optimization/subproblems.jl:67-74) and the stop test of check_convergence!
 //              (src/optimization/convergence.jl:1-31)
 //   k_derive_* rebuild the consensus state from a primal state handed in by dopf_set_state
+#include <algorithm>
+
 #include "dopf_internal.h"
 
 namespace dopf {
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(256) void k_slack(DevView v)
 {
     if (v.st->halt) return;
     __shared__ double dl[256];
+    __shared__ double red[256];
     const int tid = threadIdx.x;
     const size_t at = blockIdx.x;
     const int N = v.N, L = v.L, T = v.T;
@@ -181,27 +184,41 @@ __global__ __launch_bounds__(256) void k_slack(DevView v)
     const int sb = v.node_sto_beg[n], ns = v.node_sto_beg[n + 1] - sb;
     const int na = ng + ns;
     const double w2 = 2.0 * v.w_flow, g = v.gamma, inv = 1.0 / (w2 + g);
+    const double W = v.node_win[n];
+    // sum of the node's injection changes: a line whose slack stays active (or inactive) for EVERY change an agent
+    // of this node can make, |d| <= W, needs only this sum — the usual case; only lines with a switch point inside
+    // the window walk the agents one by one
+    double sd = 0.0;
+    for (int a = tid; a < na; a += 256)
+        sd += a < ng ? v.dltG[(size_t)(gb + a) * T + t] : v.dltS[(size_t)(sb + a - ng) * T + t];
+    const double sumD = block_sum256(sd, red);
     for (int lc = 0; lc < L; lc += 256) {
         const int l = lc + tid;
         double aU = 0.0, aK = 0.0, kap = 0.0, sU = 0.0, sK = 0.0;
+        bool walkU = false, walkK = false;
         if (l < L) {
             const double h = v.ptdf[l + L * n], f = v.flow[l + L * t], F = v.fmax[l];
             aU = (g * v.avgU[l + L * t] - w2 * (f - F)) * inv;
             aK = (g * v.avgK[l + L * t] + w2 * (f + F)) * inv;
             kap = w2 * h * inv;
+            const double reach = fabs(kap) * W;
+            if (aU - reach >= 0.0) sU = na * aU - kap * sumD;           // max(0, aU - kap d) = aU - kap d for all agents
+            else walkU = aU + reach > 0.0;                                // (else 0 for all agents)
+            if (aK - reach >= 0.0) sK = na * aK + kap * sumD;
+            else walkK = aK + reach > 0.0;
         }
-        for (int base = 0; base < na; base += 256) {
-            const int a = base + tid;
-            __syncthreads();
-            if (a < na) dl[tid] = a < ng ? v.dltG[(size_t)(gb + a) * T + t] : v.dltS[(size_t)(sb + a - ng) * T + t];
-            __syncthreads();
-            const int cnt = na - base < 256 ? na - base : 256;
-            if (l < L)
-                for (int j = 0; j < cnt; ++j) {
-                    const double d = dl[j];
-                    sU += dmax0(aU - kap * d);
-                    sK += dmax0(aK + kap * d);
-                }
+        if (__syncthreads_or(walkU || walkK)) {
+            for (int base = 0; base < na; base += 256) {
+                const int a = base + tid;
+                __syncthreads();
+                if (a < na) dl[tid] = a < ng ? v.dltG[(size_t)(gb + a) * T + t] : v.dltS[(size_t)(sb + a - ng) * T + t];
+                __syncthreads();
+                const int cnt = na - base < 256 ? na - base : 256;
+                if (walkU)
+                    for (int j = 0; j < cnt; ++j) sU += dmax0(aU - kap * dl[j]);
+                if (walkK)
+                    for (int j = 0; j < cnt; ++j) sK += dmax0(aK + kap * dl[j]);
+            }
         }
         if (l < L) {
             v.part_U[at * L + l] = sU;
@@ -331,7 +348,15 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
             const int l = (int)(rem % L), t = (int)(rem / L);
             const double *src = which ? v.part_K : v.part_U;
             double sum = 0.0;
-            for (int n = 0; n < N; ++n) sum += src[((size_t)n + (size_t)N * t) * L + l];
+            for (int n0 = 0; n0 < N; n0 += 8) {           // eight loads in flight (a plain loop waits for each one)
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int n = n0 + u;
+                    x[u] = n < N ? src[((size_t)n + (size_t)N * t) * L + l] : 0.0;
+                }
+                sum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+            }
             v.cons[(size_t)N * T + idx] = sum;
         }
     }
@@ -365,7 +390,16 @@ __device__ __forceinline__ void dual_body(const DevView &v, size_t i, double &rl
     if (i < (size_t)T) {
         const int t = (int)i;
         double sum = 0.0;
-        for (int n = 0; n < N; ++n) sum += cinj[n + (size_t)N * t] - v.demand[n + (size_t)N * t];
+        for (int n0 = 0; n0 < N; n0 += 8) {               // eight nodes in flight (one lane walks all N of them)
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int n = n0 + u;
+                x[u] = n < N ? cinj[n + (size_t)N * t] - v.demand[n + (size_t)N * t] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += x[u];
+        }
         v.s[t] = sum;
         if (UPDATE) {
             const double lo = v.lam[t], ln = lo + v.gamma * sum;          // update_duals.jl:8-13
@@ -377,7 +411,17 @@ __device__ __forceinline__ void dual_body(const DevView &v, size_t i, double &rl
     if (i < LT) {
         const int l = (int)(i % L), t = (int)(i / L);
         double f = 0.0;
-        for (int n = 0; n < N; ++n) f += v.ptdf[l + (size_t)L * n] * (cinj[n + (size_t)N * t] - v.demand[n + (size_t)N * t]);
+        for (int n0 = 0; n0 < N; n0 += 8) {               // eight rows of ptdf in flight
+            double h[8], q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int n = n0 + u < N ? n0 + u : N - 1;
+                h[u] = n0 + u < N ? v.ptdf[l + (size_t)L * n] : 0.0;
+                q[u] = cinj[n + (size_t)N * t] - v.demand[n + (size_t)N * t];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) f += h[u] * q[u];
+        }
         v.flow[i] = f;                                                    // results.jl:114
         if (UPDATE) {
             const double aU = v.invA * cU[i], aK = v.invA * cK[i];       // results.jl:108-112
@@ -400,7 +444,17 @@ __device__ __forceinline__ void price_body(const DevView &v, size_t i)
     const int N = v.N, L = v.L;
     const int n = (int)(i % N), t = (int)(i / N);
     double p = v.lam[t];
-    for (int l = 0; l < L; ++l) p += v.ptdf[l + (size_t)L * n] * (v.mu[l + (size_t)L * t] - v.rho[l + (size_t)L * t]);
+    for (int l0 = 0; l0 < L; l0 += 8) {                   // ptdfT[n + N l]: coalesced over the nodes, eight lines in flight
+        double h[8], q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int l = l0 + u < L ? l0 + u : L - 1;
+            h[u] = l0 + u < L ? v.ptdfT[n + (size_t)N * l] : 0.0;
+            q[u] = v.mu[l + (size_t)L * t] - v.rho[l + (size_t)L * t];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p += h[u] * q[u];
+    }
     v.price[i] = p;
 }
 
@@ -448,6 +502,120 @@ __global__ __launch_bounds__(256) void k_price(DevView v)
     // recomputed even after a halt: the duals are frozen then, so the values are identical
     if (i < NT) price_body(v, i);
     if (UPDATE && i == 0) {
+        Status *st = v.st;
+        if (st->halt) return;
+        const double r0 = __longlong_as_double((long long)st->resbits[0]);
+        const double r1 = __longlong_as_double((long long)st->resbits[1]);
+        const double r2 = __longlong_as_double((long long)st->resbits[2]);
+        st->resbits[0] = st->resbits[1] = st->resbits[2] = 0ull;
+        status_update(v, r0, r1, r2);
+    }
+}
+
+// Big networks, one block per timestep: the nodal injections of the timestep are staged in LDS once and every line
+// of the block reads them from there (flows = ptdf . inj is the only O(N L T) piece of the dual step); the
+// imbalance is a fixed-order block sum. The price kernel stages (mu - rho)[., t] the same way and skips the
+// ptdf^T product altogether for a timestep on which no line carries a multiplier.
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void k_dual_t(DevView v)
+{
+    if (UPDATE && v.st->halt) return;
+    extern __shared__ double q[];            // N
+    __shared__ double red[256];
+    const int tid = threadIdx.x, t = blockIdx.x;
+    const int N = v.N, L = v.L, T = v.T;
+    const size_t NT = (size_t)N * T, LT = (size_t)L * T;
+    const double *cinj = v.cons, *cU = v.cons + NT, *cK = cU + LT;
+    double part = 0.0;
+    for (int n = tid; n < N; n += 256) {
+        const double x = cinj[n + (size_t)N * t] - v.demand[n + (size_t)N * t];
+        q[n] = x;
+        v.inj[n + (size_t)N * t] = x;                                      // results.jl:58-100
+        part += x;
+    }
+    const double sum = block_sum256(part, red);                              // (barriers inside: q[] is complete)
+    double rl = 0.0, rm = 0.0, rr = 0.0;
+    if (tid == 0) {
+        v.s[t] = sum;
+        if (UPDATE) {
+            const double lo = v.lam[t], ln = lo + v.gamma * sum;             // update_duals.jl:8-13
+            v.lam_used[t] = lo;
+            v.lam[t] = ln;
+            rl = fabs(ln - lo);
+        }
+    }
+    for (int l = tid; l < L; l += 256) {
+        double f = 0.0;
+        for (int n0 = 0; n0 < N; n0 += 8) {                                  // eight rows of ptdf in flight
+            double h[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) h[u] = n0 + u < N ? v.ptdf[l + (size_t)L * (n0 + u)] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) f += h[u] * (n0 + u < N ? q[n0 + u] : 0.0);
+        }
+        const size_t i = l + (size_t)L * t;
+        v.flow[i] = f;                                                       // results.jl:114
+        if (UPDATE) {
+            const double aU = v.invA * cU[i], aK = v.invA * cK[i];          // results.jl:108-112
+            v.avgU[i] = aU;
+            v.avgK[i] = aK;
+            const double mo = v.mu[i], ro = v.rho[i], F = v.fmax[l];
+            const double mn = (mo + v.gamma * (f + aU - F)) * (aU <= v.mask_thr ? 1.0 : 0.0);   // update_duals.jl:18-25
+            const double rn = (ro + v.gamma * (aK - f - F)) * (aK <= v.mask_thr ? 1.0 : 0.0);   // :30-37
+            v.mu_used[i] = mo; v.rho_used[i] = ro;
+            v.mu[i] = mn; v.rho[i] = rn;
+            rm = fmax(rm, fabs(mn - mo));
+            rr = fmax(rr, fabs(rn - ro));
+        }
+    }
+    if (UPDATE) {
+        // block max (order independent), then one atomic per block and residual
+        __syncthreads();
+        red[tid] = rm;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmax(red[tid], red[tid + s]); __syncthreads(); }
+        const double bm = red[0];
+        __syncthreads();
+        red[tid] = rr;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmax(red[tid], red[tid + s]); __syncthreads(); }
+        if (tid == 0) {
+            if (rl > 0.0) atomic_max_pos(&v.st->resbits[0], rl);
+            if (bm > 0.0) atomic_max_pos(&v.st->resbits[1], bm);
+            if (red[0] > 0.0) atomic_max_pos(&v.st->resbits[2], red[0]);
+            if (t == 0) v.st->total_cost = v.cons[NT + 2 * LT];
+        }
+    }
+}
+
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void k_price_t(DevView v)
+{
+    extern __shared__ double d[];            // L
+    const int tid = threadIdx.x, t = blockIdx.x;
+    const int N = v.N, L = v.L;
+    int nz = 0;
+    for (int l = tid; l < L; l += 256) {
+        const double x = v.mu[l + (size_t)L * t] - v.rho[l + (size_t)L * t];
+        d[l] = x;
+        nz |= x != 0.0;
+    }
+    nz = __syncthreads_or(nz);
+    // recomputed even after a halt: the duals are frozen then, so the values are identical
+    const double lam = v.lam[t];
+    for (int n = tid; n < N; n += 256) {
+        double p = lam;
+        if (nz)
+            for (int l0 = 0; l0 < L; l0 += 8) {                              // ptdfT[n + N l]: coalesced over the nodes
+                double h[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) h[u] = l0 + u < L ? v.ptdfT[n + (size_t)N * (l0 + u)] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p += h[u] * (l0 + u < L ? d[l0 + u] : 0.0);
+            }
+        v.price[n + (size_t)N * t] = p;
+    }
+    if (UPDATE && t == 0 && tid == 0) {
         Status *st = v.st;
         if (st->halt) return;
         const double r0 = __longlong_as_double((long long)st->resbits[0]);
@@ -545,6 +713,11 @@ void launch_dual(const DevView &v, hipStream_t s)
         hipLaunchKernelGGL(k_dual_price_small<true>, dim3(1), dim3(256), 0, s, v);
         return;
     }
+    if ((size_t)std::max(v.N, v.L) * sizeof(double) <= 48 * 1024) {
+        hipLaunchKernelGGL(k_dual_t<true>, dim3(v.T), dim3(256), (size_t)v.N * sizeof(double), s, v);
+        hipLaunchKernelGGL(k_price_t<true>, dim3(v.T), dim3(256), (size_t)v.L * sizeof(double), s, v);
+        return;
+    }
     hipLaunchKernelGGL(k_dual<true>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_price<true>, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, v);
 }
@@ -586,6 +759,11 @@ void launch_derive(const DevView &v, hipStream_t s, bool from_primal)
     }
     if (n1 <= kSmallConsensus) {
         hipLaunchKernelGGL(k_dual_price_small<false>, dim3(1), dim3(256), 0, s, v);
+        return;
+    }
+    if ((size_t)std::max(v.N, v.L) * sizeof(double) <= 48 * 1024) {
+        hipLaunchKernelGGL(k_dual_t<false>, dim3(v.T), dim3(256), (size_t)v.N * sizeof(double), s, v);
+        hipLaunchKernelGGL(k_price_t<false>, dim3(v.T), dim3(256), (size_t)v.L * sizeof(double), s, v);
         return;
     }
     hipLaunchKernelGGL(k_dual<false>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, v);
