@@ -288,6 +288,8 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         schunk = (schunk + NG - 1) / NG * NG;
         make_items(snode, N, schunk, sitems, nsb, nsib);
     }
+    v.maxNodeAgents = 0;
+    for (int n = 0; n < N; ++n) v.maxNodeAgents = std::max(v.maxNodeAgents, (ngb[n + 1] - ngb[n]) + (nsb[n + 1] - nsb[n]));
     v.nGenItems = (int)gitems.size();
     v.nStoItems = (int)sitems.size();
     {

@@ -42,6 +42,7 @@ struct Status {
 
 struct DevView {
     int N, L, T, G, S, M2;          // M2 = 2L
+    int maxNodeAgents;              // most agents (generators + storages) at one node
     int nGenItems, nStoItems;
     int genTT, genR;                // generator block tiling: TT = min(T, 512) timesteps x R agents
     int genSkip;                    // pair kernel with row skipping (blocks sweep >= 8 passes of agents)

@@ -77,36 +77,50 @@ __global__ __launch_bounds__(64) void k_tables(DevView v)
     // ---- classify the 2L candidate kinks; keep the ones inside [-W, W] in list order
     double s0part = 0.0, left = 0.0, pz = 0.0;
     int c = 0;
-    for (int base = 0; base < M2; base += 64) {
-        const int i = base + lane;
-        double kv = INFINITY, jv = 0.0;
-        if (i < M2) {
-            const int l = i >> 1;
-            const double h = v.ptdf[l + L * n];
-            if (h != 0.0) {
-                const double f = v.flow[l + L * t], F = v.fmax[l];
-                const double dj = w2 * h * h * (1.0 - act);
-                if ((i & 1) == 0) {          // U switches: active where h*dlt < ...
-                    kv = (g * v.avgU[l + L * t] / w2 - f + F) / h;
-                    jv = h > 0.0 ? dj : -dj;
-                    s0part += w2 * h * h * (1.0 + act);     // at -inf exactly one of U, K is active
-                    pz += line_term(v, l, t, h, 0.0);       // Psi(0), network part
-                } else {                     // K switches
-                    kv = (-g * v.avgK[l + L * t] / w2 - f - F) / h;
-                    jv = h > 0.0 ? -dj : dj;
+    for (int base = 0; base < M2; base += 64 * 4) {          // four passes of 64 candidates, their loads issued together
+        double hh[4], ff[4], FF[4], au[4], ak[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + 64 * u + lane;
+            const int l = (i < M2 ? i : 0) >> 1;
+            hh[u] = v.ptdf[l + L * n]; ff[u] = v.flow[l + L * t]; FF[u] = v.fmax[l];
+            au[u] = v.avgU[l + L * t]; ak[u] = v.avgK[l + L * t];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + 64 * u + lane;
+            if (base + 64 * u >= M2) break;                    // (wave-uniform)
+            double kv = INFINITY, jv = 0.0;
+            if (i < M2) {
+                const double h = hh[u];
+                if (h != 0.0) {
+                    const double f = ff[u], F = FF[u];
+                    const double dj = w2 * h * h * (1.0 - act);
+                    if ((i & 1) == 0) {          // U switches: active where h*dlt < ...
+                        kv = (g * au[u] / w2 - f + F) / h;
+                        jv = h > 0.0 ? dj : -dj;
+                        s0part += w2 * h * h * (1.0 + act);     // at -inf exactly one of U, K is active
+                        // Psi(0), network part (line_term at dl = 0 with the values already loaded)
+                        const double U = dmax0((g * au[u] - w2 * (f - F)) / (w2 + g));
+                        const double K = dmax0((g * ak[u] + w2 * (f + F)) / (w2 + g));
+                        pz += w2 * h * ((f + U - F) - (K - f - F));
+                    } else {                     // K switches
+                        kv = (-g * ak[u] / w2 - f - F) / h;
+                        jv = h > 0.0 ? -dj : dj;
+                    }
                 }
             }
+            const bool fin = kv < INFINITY;                      // (also false for NaN)
+            if (fin && kv < -W) left += jv;
+            const bool in = fin && kv >= -W && kv <= W;
+            const unsigned long long mask = __ballot(in);
+            if (in) {
+                const int pos = c + __popcll(mask & ((1ull << lane) - 1ull));
+                key[pos] = kv;
+                jmp[pos] = jv;
+            }
+            c += __popcll(mask);
         }
-        const bool fin = kv < INFINITY;                      // (also false for NaN)
-        if (fin && kv < -W) left += jv;
-        const bool in = fin && kv >= -W && kv <= W;
-        const unsigned long long mask = __ballot(in);
-        if (in) {
-            const int pos = c + __popcll(mask & ((1ull << lane) - 1ull));
-            key[pos] = kv;
-            jmp[pos] = jv;
-        }
-        c += __popcll(mask);
     }
     const double slope_left = g + wave_sum64(s0part) + wave_sum64(left);    // slope just right of -W
     const double psiZ = v.price[n + N * t] + g * v.s[t] + wave_sum64(pz);
@@ -171,56 +185,100 @@ void launch_tables(const DevView &v, hipStream_t s)
 // ------------------------------------------------------------------------------------------------
 // slack sums (L > 0): one block per (n,t), threads <-> lines, agents staged through LDS
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_slack(DevView v)
+// sum_a max(0, base + k d_a) over the node's agents at one timestep: the staged ones from LDS, eight reads in
+// flight, the rest (nodes with more agents than the tile holds) from memory; list order
+__device__ __forceinline__ double walk_sum(const DevView &v, const double *dtile, int tt, int t, int T, int gb, int ng,
+                                           int sb, int na, int cap, double base, double k)
+{
+    double acc = 0.0;
+    const int nl = na < cap ? na : cap;
+    for (int a0 = 0; a0 < nl; a0 += 8) {
+        double d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d[u] = dtile[(a0 + u < nl ? a0 + u : a0) * 33 + tt];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += a0 + u < nl ? dmax0(base + k * d[u]) : 0.0;
+    }
+    for (int a = nl; a < na; ++a)
+        acc += dmax0(base + k * (a < ng ? v.dltG[(size_t)(gb + a) * T + t] : v.dltS[(size_t)(sb + a - ng) * T + t]));
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_slack(DevView v, const int cap)
 {
     if (v.st->halt) return;
-    __shared__ double dl[256];
+    constexpr int TS = 32;                   // timesteps per block: the agents' changes are read along t (coalesced)
     __shared__ double red[256];
+    __shared__ double sumD[TS];
+    extern __shared__ double dtile[];        // [a * 33 + tt] for the node's first `cap` agents (padded rows)
     const int tid = threadIdx.x;
-    const size_t at = blockIdx.x;
     const int N = v.N, L = v.L, T = v.T;
-    const int n = (int)(at % N), t = (int)(at / N);
+    const int TC = (T + TS - 1) / TS;
+    const int n = blockIdx.x / TC, t0 = (blockIdx.x - n * TC) * TS;
     const int gb = v.node_gen_beg[n], ng = v.node_gen_beg[n + 1] - gb;
     const int sb = v.node_sto_beg[n], ns = v.node_sto_beg[n + 1] - sb;
     const int na = ng + ns;
     const double w2 = 2.0 * v.w_flow, g = v.gamma, inv = 1.0 / (w2 + g);
     const double W = v.node_win[n];
-    // sum of the node's injection changes: a line whose slack stays active (or inactive) for EVERY change an agent
-    // of this node can make, |d| <= W, needs only this sum — the usual case; only lines with a switch point inside
-    // the window walk the agents one by one
-    double sd = 0.0;
-    for (int a = tid; a < na; a += 256)
-        sd += a < ng ? v.dltG[(size_t)(gb + a) * T + t] : v.dltS[(size_t)(sb + a - ng) * T + t];
-    const double sumD = block_sum256(sd, red);
-    for (int lc = 0; lc < L; lc += 256) {
-        const int l = lc + tid;
-        double aU = 0.0, aK = 0.0, kap = 0.0, sU = 0.0, sK = 0.0;
-        bool walkU = false, walkK = false;
-        if (l < L) {
-            const double h = v.ptdf[l + L * n], f = v.flow[l + L * t], F = v.fmax[l];
-            aU = (g * v.avgU[l + L * t] - w2 * (f - F)) * inv;
-            aK = (g * v.avgK[l + L * t] + w2 * (f + F)) * inv;
-            kap = w2 * h * inv;
-            const double reach = fabs(kap) * W;
-            if (aU - reach >= 0.0) sU = na * aU - kap * sumD;           // max(0, aU - kap d) = aU - kap d for all agents
-            else walkU = aU + reach > 0.0;                                // (else 0 for all agents)
-            if (aK - reach >= 0.0) sK = na * aK + kap * sumD;
-            else walkK = aK + reach > 0.0;
-        }
-        if (__syncthreads_or(walkU || walkK)) {
-            for (int base = 0; base < na; base += 256) {
-                const int a = base + tid;
-                __syncthreads();
-                if (a < na) dl[tid] = a < ng ? v.dltG[(size_t)(gb + a) * T + t] : v.dltS[(size_t)(sb + a - ng) * T + t];
-                __syncthreads();
-                const int cnt = na - base < 256 ? na - base : 256;
-                if (walkU)
-                    for (int j = 0; j < cnt; ++j) sU += dmax0(aU - kap * dl[j]);
-                if (walkK)
-                    for (int j = 0; j < cnt; ++j) sK += dmax0(aK + kap * dl[j]);
+    // sum of the node's injection changes per timestep: a line whose slack stays active (or inactive) for EVERY
+    // change an agent of this node can make, |d| <= W, needs only this sum — the usual case; only (line, timestep)
+    // pairs with a switch point inside the window walk the agents one by one
+    {
+        const int r = tid >> 5, tt = tid & 31, t = t0 + tt;
+        double sd = 0.0;
+        if (t < T)
+            for (int a0 = r; a0 < na; a0 += 32) {         // four rows in flight per lane
+                double d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int a = a0 + 8 * u;
+                    const int aa = a < na ? a : r;            // (a valid row; value dropped below)
+                    const double x = aa < ng ? v.dltG[(size_t)(gb + aa) * T + t] : v.dltS[(size_t)(sb + aa - ng) * T + t];
+                    d[u] = a < na ? x : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int a = a0 + 8 * u;
+                    if (a < na && a < cap) dtile[a * 33 + tt] = d[u];
+                    sd += d[u];
+                }
             }
+        red[tid] = sd;
+        __syncthreads();
+        if (r == 0) {
+            double sum = 0.0;
+            for (int q = 0; q < 8; ++q) sum += red[q * 32 + tt];
+            sumD[tt] = sum;
         }
-        if (l < L) {
+        __syncthreads();
+    }
+    const int nt = min(TS, T - t0), np = L * nt;
+    for (int p0 = tid; p0 < np; p0 += 4 * 256) {          // pairs (l fastest: coalesced), four per lane in flight
+        double h[4], f[4], F[4], cu[4], ck[4];
+        int ls[4], tts[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + 256 * u < np ? p0 + 256 * u : tid;      // (a valid pair; result dropped below)
+            const int tt = p / L, l = p - tt * L, t = t0 + tt;
+            ls[u] = l; tts[u] = tt;
+            h[u] = v.ptdf[l + L * n]; f[u] = v.flow[l + L * t]; F[u] = v.fmax[l];
+            cu[u] = v.avgU[l + L * t]; ck[u] = v.avgK[l + L * t];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (p0 + 256 * u >= np) continue;
+            const int l = ls[u], tt = tts[u], t = t0 + tt;
+            const double aU = (g * cu[u] - w2 * (f[u] - F[u])) * inv;
+            const double aK = (g * ck[u] + w2 * (f[u] + F[u])) * inv;
+            const double kap = w2 * h[u] * inv, reach = fabs(kap) * W, sD = sumD[tt];
+            double sU = 0.0, sK = 0.0;
+            if (aU - reach >= 0.0) sU = na * aU - kap * sD;       // max(0, aU - kap d) = aU - kap d for all agents
+            else if (aU + reach > 0.0)                            // (else 0 for all agents)
+                sU = walk_sum(v, dtile, tt, t, T, gb, ng, sb, na, cap, aU, -kap);
+            if (aK - reach >= 0.0) sK = na * aK + kap * sD;
+            else if (aK + reach > 0.0)
+                sK = walk_sum(v, dtile, tt, t, T, gb, ng, sb, na, cap, aK, kap);
+            const size_t at = (size_t)n + (size_t)N * t;
             v.part_U[at * L + l] = sU;
             v.part_K[at * L + l] = sK;
         }
@@ -230,7 +288,8 @@ __global__ __launch_bounds__(256) void k_slack(DevView v)
 void launch_slack(const DevView &v, hipStream_t s)
 {
     if (v.L == 0) return;
-    hipLaunchKernelGGL(k_slack, dim3(v.N * v.T), dim3(256), 0, s, v);
+    const int cap = std::min(v.maxNodeAgents, 240);         // 240 agents x 33 doubles = 62 KB of LDS
+    hipLaunchKernelGGL(k_slack, dim3(v.N * ((v.T + 31) / 32)), dim3(256), (size_t)cap * 33 * sizeof(double), s, v, cap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -278,10 +337,12 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
         }
         red[tid] = acc;
         __syncthreads();
+        const bool direct = RB == 1 && !v.sliceDual;       // one slice per node: its sum IS the node's sum
         if (r == 0 && t < T) {
             double sum = 0.0;
             for (int q = 0; q < R; ++q) sum += red[q * TT + tt];
-            v.part2[((size_t)n * RB + rb) * T + t] = sum;
+            if (direct) v.cons[n + (size_t)N * t] = sum;
+            else v.part2[((size_t)n * RB + rb) * T + t] = sum;
         }
         // cost partials ride with the first node's slices of the first timestep chunk
         if (n == 0 && tcx == 0) {
@@ -291,9 +352,12 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
             for (int i = c0 + tid; i < c1; i += 256)
                 c += i < v.nGenItems ? v.part_gcost[i] : v.part_scost[i - v.nGenItems] + v.part_scost_w[i - v.nGenItems];
             c = block_sum256(c, red);
-            if (tid == 0) v.part2_cost[rb] = c;
+            if (tid == 0) {
+                if (direct) v.cons[(size_t)N * T + 2 * (size_t)L * T] = c;
+                else v.part2_cost[rb] = c;
+            }
         }
-        if (v.sliceDual) return;        // the dual kernel adds the slices (and the cost slices) itself
+        if (v.sliceDual || direct) return;      // slices added by the dual kernel / nothing left to add
         // publish, take a ticket; the last block of this (node, timestep chunk) finishes the sum.
         // Hand-off per cdna_hip_programming.md G16: every storing wave drains its stores, the block meets,
         // ONE lane releases at agent scope and takes the ticket; the last block's lane acquires, the block
