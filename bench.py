@@ -29,7 +29,12 @@ WORKLOADS = {
     "config2": (2, "synthetic 50k agents (45455 gen + 4545 storage), 96 timesteps, copper plate (BASELINE configs[2])"),
     "config3": (3, "synthetic 118-node/186-line network, 100k agents, 168 timesteps (BASELINE configs[3], graph is synthetic)"),
     "config4": (4, "synthetic 1M agents (909091 gen + 90909 storage), 24 timesteps, copper plate (BASELINE configs[4])"),
+    # BASELINE configs[3] is an 8-GPU configuration: this is one GPU's eighth of its agents on the full network
+    # (with --gpus 8 every rank owns such a share: the configuration itself)
+    "config3-share": (3, "one GPU's share (12.5k of 100k agents) of the synthetic 118-node/186-line network, 168 timesteps "
+                         "(BASELINE configs[3] is an 8-GPU run; graph is synthetic)"),
 }
+SHARE = {"config3-share": 0.125}
 
 
 def algorithmic_bytes(G, S, T, N, L):
@@ -41,7 +46,7 @@ def algorithmic_bytes(G, S, T, N, L):
     return gen, sto, shared
 
 
-def cpu_baseline(pp, gamma, budget_s=20.0):
+def cpu_baseline(pp, gamma, w_flow=10.0, budget_s=20.0):
     """Oracle (exact mode) on the host cores: a bounded number of iterations of the SAME problem."""
     import numpy as np  # noqa: F401
     from decentralopf_jl_amd import _capi
@@ -50,7 +55,7 @@ def cpu_baseline(pp, gamma, budget_s=20.0):
         ge.build()
     api = _capi.CApi(ge.ORACLE_LIB, "oracle_")
     cores = os.cpu_count() or 1
-    e = _capi.Engine(api, params=_capi.default_params(gamma=gamma, eps=0.0), mode=1, **pp.engine_kwargs())
+    e = _capi.Engine(api, params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0), mode=1, **pp.engine_kwargs())
     e.set_threads(cores)
     t0 = time.perf_counter()
     e.iterate(1)
@@ -77,6 +82,7 @@ def main():
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; marks the line invalid)")
     ap.add_argument("--gamma", type=float, default=None, help="ADMM penalty (BASELINE's rho); default 1/A (convergent)")
+    ap.add_argument("--w-flow", type=float, default=None, help="weight of the flow-consensus terms (reference: 10); default 10 without lines, 1/A with")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-iters", type=int, default=32)
     ap.add_argument("--overlap", action="store_true", help="fork the storage kernel onto a side stream")
@@ -117,7 +123,7 @@ def main():
 
     idx, desc = WORKLOADS[args.workload]
     # weak scaling: every rank owns one full grid of the workload (own seed), demand adds up
-    base = synth.baseline_config(idx, scale=args.scale)
+    base = synth.baseline_config(idx, scale=args.scale * SHARE.get(args.workload, 1.0))
     if world > 1:
         cfg = dict(base.meta)
         pp = synth.synthetic_case(cfg["n_gen"], cfg["n_sto"], cfg["T"], N=cfg["N"], L=cfg["L"], seed=synth.SEED + rank)
@@ -131,9 +137,13 @@ def main():
     A_local = pp.G + pp.S
     A_global = A_local * world
     gamma = args.gamma if args.gamma is not None else 1.0 / A_global
+    # flow-consensus weight: the reference's literal 10 with lines makes every agent undo the whole line violation on
+    # its own, an all-on/all-off 2-cycle for more than a few dozen agents whatever gamma is; it has to shrink with the
+    # number of agents like gamma does (1/A converges on the synthetic network). Irrelevant on a copper plate.
+    w_flow = args.w_flow if args.w_flow is not None else (10.0 if pp.L == 0 else 1.0 / A_global)
 
     if not sharded:
-        eng = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, eps=0.0, device=local_rank,
+        eng = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank,
                                                                         flags=args.flags | (_capi.F_OVERLAP_AGENTS if args.overlap else 0)),
                            **pp.engine_kwargs())
         step = lambda n: eng.iterate(n)
@@ -142,7 +152,7 @@ def main():
         from decentralopf_jl_amd.sharded import ShardedADMM
         # every rank already holds its own grid: a 1-way "shard" of its local problem, global agent count
         # passed explicitly; the all-reduce runs over all ranks on the engine's own stream
-        sh = ShardedADMM(pp, 0, 1, gamma=gamma, eps=0.0, device=local_rank, n_agents_global_override=A_global)
+        sh = ShardedADMM(pp, 0, 1, gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank, n_agents_global_override=A_global)
         st, tens = sh.stream, sh._tensor
 
         def _all_reduce():
@@ -181,7 +191,7 @@ def main():
     # `steady` = the last `timed_iters` of them (no cold-start or structure-change iterations left in there).
     timing = steady = None
     if not sharded:
-        er = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, eps=0.0, device=local_rank, flags=args.flags),
+        er = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank, flags=args.flags),
                           **pp.engine_kwargs())
         er.iterate(args.warmup)
         tail = max(1, min(args.timed_iters, args.steps))
@@ -206,7 +216,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "description": desc, "agents_per_gpu": A_local,
                        "generators_per_gpu": pp.G, "storages_per_gpu": pp.S, "timesteps": pp.T,
-                       "nodes": pp.N, "lines": pp.L, "gamma": gamma, "w_flow": 10.0, "w_prox": 1.0,
+                       "nodes": pp.N, "lines": pp.L, "gamma": gamma, "w_flow": w_flow, "w_prox": 1.0,
                        "parallelism": f"agents sharded x{world}, 1 all-reduce of {(pp.N + 2 * pp.L) * pp.T + 1} f64 per iteration"
                        if world > 1 else "single GPU"},
             "iters_per_sec": args.steps / dt,
@@ -272,7 +282,7 @@ def main():
         if not sharded:
             # the other half of BASELINE's metric: wall time until every |dual change| < 1e-3, from the zero state
             budget = int(max(64, min(100000, 10.0 * args.steps / dt)))     # at most ~10 s of iterations
-            e2 = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, eps=1e-3, max_iters=budget, device=local_rank, flags=args.flags),
+            e2 = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=1e-3, max_iters=budget, device=local_rank, flags=args.flags),
                               **pp.engine_kwargs())
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -289,12 +299,13 @@ def main():
         if not sharded and not args.no_also and args.scale == 1.0:
             # the other BASELINE configurations that fit one GPU, same engine, short runs (reported, not the metric)
             also = []
-            for wl in ("config1", "config4", "config2"):
+            for wl in ("config1", "config4", "config2", "config3-share"):
                 if wl == args.workload:
                     continue
-                ppx = synth.baseline_config(WORKLOADS[wl][0])
+                ppx = synth.baseline_config(WORKLOADS[wl][0], scale=SHARE.get(wl, 1.0))
                 Ax = ppx.G + ppx.S
-                ex = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=1.0 / Ax, eps=0.0, device=local_rank),
+                ex = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=1.0 / Ax, w_flow=10.0 if ppx.L == 0 else 1.0 / Ax,
+                                                                               eps=0.0, device=local_rank),
                                   **ppx.engine_kwargs())
                 ex.iterate(args.warmup)
                 torch.cuda.synchronize()
@@ -308,7 +319,7 @@ def main():
                 ex.close()
             out["also"] = also
         if not sharded and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pp, gamma)
+            out["cpu_baseline"] = cpu_baseline(pp, gamma, w_flow)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
