@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; marks the line invalid)")
     ap.add_argument("--gamma", type=float, default=None, help="ADMM penalty (BASELINE's rho); default 1/A (convergent)")
-    ap.add_argument("--w-flow", type=float, default=None, help="weight of the flow-consensus terms (reference: 10); default 10 without lines, 1/A with")
+    ap.add_argument("--w-flow", type=float, default=None, help="weight of the flow-consensus terms (reference: 10); default 10 without lines, 0.3/A with")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-iters", type=int, default=32)
     ap.add_argument("--overlap", action="store_true", help="fork the storage kernel onto a side stream")
@@ -139,8 +139,8 @@ def main():
     gamma = args.gamma if args.gamma is not None else 1.0 / A_global
     # flow-consensus weight: the reference's literal 10 with lines makes every agent undo the whole line violation on
     # its own, an all-on/all-off 2-cycle for more than a few dozen agents whatever gamma is; it has to shrink with the
-    # number of agents like gamma does (1/A converges on the synthetic network). Irrelevant on a copper plate.
-    w_flow = args.w_flow if args.w_flow is not None else (10.0 if pp.L == 0 else 1.0 / A_global)
+    # number of agents like gamma does (0.3/A converges on the synthetic networks tried). Irrelevant on a copper plate.
+    w_flow = args.w_flow if args.w_flow is not None else (10.0 if pp.L == 0 else 0.3 / A_global)
 
     if not sharded:
         eng = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank,
@@ -304,7 +304,7 @@ def main():
                     continue
                 ppx = synth.baseline_config(WORKLOADS[wl][0], scale=SHARE.get(wl, 1.0))
                 Ax = ppx.G + ppx.S
-                ex = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=1.0 / Ax, w_flow=10.0 if ppx.L == 0 else 1.0 / Ax,
+                ex = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=1.0 / Ax, w_flow=10.0 if ppx.L == 0 else 0.3 / Ax,
                                                                                eps=0.0, device=local_rank),
                                   **ppx.engine_kwargs())
                 ex.iterate(args.warmup)

@@ -315,6 +315,29 @@ def test_hip_config1_reaches_central_optimum(hip_api):
     assert abs(e.get_consensus()[4] - opt) / opt < 1e-3
 
 
+@pytest.mark.parametrize("fmax_factor,congested", [(1.5, False), (1.0, True)])
+def test_hip_network_reaches_central_optimum(hip_api, fmax_factor, congested):
+    """12 nodes / 18 lines, 330 agents x 12: with the flow-consensus weight scaled like gamma (0.3/A; the reference's
+    literal 10 flips all agents between their bounds at this size) the run converges to the central LP optimum
+    (tests/central_lp.py). With binding line limits (fmax = the merit-order flows) the masked mu/rho update keeps
+    moving above the 1e-3 stop test, but cost and flows are at the LP optimum."""
+    pp = synth.synthetic_case(300, 30, 12, N=12, L=18, seed=23, fmax_factor=fmax_factor, fmax_min=20)
+    A = pp.G + pp.S
+    opt = solve_central(pp)["objective"]
+    e = make_engine(hip_api, pp, gamma=1.0 / A, w_flow=0.3 / A, eps=1e-3, max_iters=4000)
+    done, conv = e.iterate(4000)
+    inj, aU, aK, flow, cost = e.get_consensus()
+    assert abs(cost - opt) / opt < 1e-3
+    # (congested: the iterate keeps wandering around the optimum, up to ~10 % over the limit of a 20 MW line)
+    assert ((np.abs(flow) - pp.f_max[:, None]) / pp.f_max[:, None]).max() < (0.2 if congested else 1e-6)
+    assert np.abs(inj.sum(axis=0)).max() < 1e-3 * pp.demand.sum(axis=0).max()
+    if congested:
+        assert e.get_duals()[1].max() > 0.1                 # a line limit binds: its multiplier is up
+    else:
+        assert conv and done < 1500
+    assert e.solver_failures() == 0
+
+
 def _random_storage_case(rng, T):
     """Copper-plate case with adversarial storage parameters and a random feasible previous iterate."""
     G, S = int(rng.integers(3, 12)), int(rng.integers(4, 24))
