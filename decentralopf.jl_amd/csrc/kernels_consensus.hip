@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_slack(DevView v, const int cap)
 void launch_slack(const DevView &v, hipStream_t s)
 {
     if (v.L == 0) return;
-    const int cap = std::min(v.maxNodeAgents, 240);         // 240 agents x 33 doubles = 62 KB of LDS
+    const int cap = std::min(v.maxNodeAgents, 224);         // 224 agents x 33 doubles = 58 KB (+ 2.3 KB static: under 64 KB)
     hipLaunchKernelGGL(k_slack, dim3(v.N * ((v.T + 31) / 32)), dim3(256), (size_t)cap * 33 * sizeof(double), s, v, cap);
 }
 
