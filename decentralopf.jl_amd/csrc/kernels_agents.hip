@@ -64,27 +64,37 @@ __global__ __launch_bounds__(512) void k_gen_update(DevView v)
                 const double *beta = v.tb_beta + at * v.M2, *psi = v.tb_psi + at * v.M2;
                 const double *slope = v.tb_slope + at * (v.M2 + 1);
                 const double psi0 = v.tb_psi0[at];
-                for (int g = it.a0 + r; g < it.a1; g += R) {
-                    const size_t e = (size_t)g * T + t;
-                    const double mc = v.gen_mc[g], pm = v.gen_pmax[g];
-                    const double p0 = v.P[e];
-                    double dl;
-                    if (m == 0) {
-                        dl = -(mc + psi0) / (slope[0] + w);
-                    } else {
-                        int lo = 0, hi = m;           // first kink with psi + w beta >= -mc
-                        while (lo < hi) {
-                            const int mid = (lo + hi) >> 1;
-                            if (psi[mid] + w * beta[mid] >= -mc) hi = mid; else lo = mid + 1;
-                        }
-                        const int a = lo < m ? lo : m - 1;
-                        dl = beta[a] - (mc + psi[a] + w * beta[a]) / (slope[lo] + w);
+                const double slope0 = slope[0];
+                for (int g0 = it.a0 + r; g0 < it.a1; g0 += 4 * R) {          // four agents' rows in flight per lane
+                    double mc[4], pm[4], p0[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int g = g0 + u * R < it.a1 ? g0 + u * R : g0;
+                        mc[u] = v.gen_mc[g]; pm[u] = v.gen_pmax[g]; p0[u] = v.P[(size_t)g * T + t];
                     }
-                    const double pn = clampd(p0 + dl, 0.0, pm);
-                    v.P[e] = pn;
-                    v.dltG[e] = pn - p0;
-                    acc += pn;
-                    cost += mc * pn;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int g = g0 + u * R;
+                        if (g >= it.a1) break;
+                        const size_t e = (size_t)g * T + t;
+                        double dl;
+                        if (m == 0) {
+                            dl = -(mc[u] + psi0) / (slope0 + w);
+                        } else {
+                            int lo = 0, hi = m;           // first kink with psi + w beta >= -mc
+                            while (lo < hi) {
+                                const int mid = (lo + hi) >> 1;
+                                if (psi[mid] + w * beta[mid] >= -mc[u]) hi = mid; else lo = mid + 1;
+                            }
+                            const int a = lo < m ? lo : m - 1;
+                            dl = beta[a] - (mc[u] + psi[a] + w * beta[a]) / (slope[lo] + w);
+                        }
+                        const double pn = clampd(p0[u] + dl, 0.0, pm[u]);
+                        v.P[e] = pn;
+                        v.dltG[e] = pn - p0[u];
+                        acc += pn;
+                        cost += mc[u] * pn;
+                    }
                 }
             }
         }
