@@ -129,6 +129,7 @@ def main():
         pp = synth.synthetic_case(cfg["n_gen"], cfg["n_sto"], cfg["T"], N=cfg["N"], L=cfg["L"], seed=synth.SEED + rank)
         if cfg["L"] > 0:          # one network for everybody: rank 0's
             pp.ptdf, pp.f_max = base.ptdf, base.f_max * world
+        own_demand = pp.demand.copy()
         dem = torch.tensor(pp.demand, dtype=torch.float64, device="cuda")
         dist.all_reduce(dem)
         pp.demand = dem.cpu().numpy()
@@ -189,10 +190,21 @@ def main():
     # hipGraphs (no place for events), so the SAME iterations — W warm-up, then K — are run again on a fresh engine,
     # the K launched kernel by kernel with an event pair around each: `timing` = mean over iterations W..W+K-1,
     # `steady` = the last `timed_iters` of them (no cold-start or structure-change iterations left in there).
+    # With N > 1 ranks the replay is rank 0's own grid as a single-GPU problem (its own demand, gamma = 1/A_local): the
+    # kernels one GPU runs per iteration, without the collective.
     timing = steady = None
-    if not sharded:
-        er = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank, flags=args.flags),
-                          **pp.engine_kwargs())
+    if rank == 0:
+        if world > 1:
+            import copy
+            ppr = copy.copy(pp)
+            ppr.demand = own_demand
+            g_r, wf_r = 1.0 / A_local, (w_flow if pp.L == 0 else 0.3 / A_local)
+            if pp.L > 0:
+                ppr.f_max = pp.f_max / world
+        else:
+            ppr, g_r, wf_r = pp, gamma, w_flow
+        er = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=g_r, w_flow=wf_r, eps=0.0, device=local_rank, flags=args.flags),
+                          **ppr.engine_kwargs())
         er.iterate(args.warmup)
         tail = max(1, min(args.timed_iters, args.steps))
         parts, left = [], args.steps - tail
