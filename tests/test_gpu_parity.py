@@ -53,6 +53,7 @@ SYNTH = [
     ("copper-T1", dict(n_gen=9, n_sto=4, T=1, seed=9), dict(gamma=0.05), 1, 20, 1e-9),
     ("copper-T6", dict(n_gen=20, n_sto=5, T=6), dict(gamma=0.05), 1, 40, 1e-9),
     ("copper-T24-lps8", dict(n_gen=100, n_sto=30, T=24, seed=2), dict(gamma=0.01), 1, 40, 1e-9),
+    ("copper-T23-odd", dict(n_gen=300, n_sto=40, T=23, seed=9), dict(gamma=0.003), 1, 25, 1e-9),
     ("copper-T40-lps16", dict(n_gen=50, n_sto=20, T=40, seed=5), dict(gamma=0.02), 1, 15, 1e-9),
     ("copper-T96-lps32", dict(n_gen=50, n_sto=20, T=96, seed=3), dict(gamma=0.02), 1, 15, 1e-9),
     ("copper-T168-lps64", dict(n_gen=50, n_sto=20, T=168, seed=4), dict(gamma=0.02), 1, 8, 1e-9),
