@@ -503,6 +503,12 @@ static int literal_storage(oracle_ctx *c, int s, double *Dn, double *Cn, double 
 /* EXACT mode: SURVEY.md section 9.4                                                           */
 /* ------------------------------------------------------------------------------------------ */
 
+/* A PTDF entry below this is rounding noise of the matrix inverse (exact value 0): its kinks would sit at
+ * |beta| ~ 1e15 and beyond, where Psi(beta) and "beta - 1" lose all precision, while its share of Psi is below
+ * 1e-9 w_flow. The exact mode's tables skip such lines (found by scripts/fuzz_parity.py: HIP and the literal mode
+ * agreed, the exact mode did not); the literal mode and the flow/slack sums keep every entry. */
+#define PTDF_NOISE 1e-12
+
 /* closed-form slacks for a change dlt of the agent's net injection at node n */
 static double slackU(const oracle_ctx *c, int l, int t, double h, double dlt)
 {
@@ -527,7 +533,7 @@ static double psi_eval(const oracle_ctx *c, int n, int t, double dlt)
     double v = c->price[n + c->N * t] + g * (c->s_prev[t] + dlt);
     for (int l = 0; l < L; ++l) {
         const double h = c->ptdf[l + L * n];
-        if (h == 0.0) continue;
+        if (fabs(h) < PTDF_NOISE) continue;
         const double f = c->f_prev[l + L * t] + h * dlt, F = c->fmax[l];
         v += w2 * h * ((f + slackU(c, l, t, h, dlt) - F) - (slackK(c, l, t, h, dlt) - f - F));
     }
@@ -541,7 +547,7 @@ static double psi_slope(const oracle_ctx *c, int n, int t, double dlt)
     double v = g;
     for (int l = 0; l < L; ++l) {
         const double h = c->ptdf[l + L * n];
-        if (h == 0.0) continue;
+        if (fabs(h) < PTDF_NOISE) continue;
         v += w2 * h * h * ((slackU(c, l, t, h, dlt) > 0 ? act : 1.0) + (slackK(c, l, t, h, dlt) > 0 ? act : 1.0));
     }
     return v;
@@ -564,7 +570,7 @@ static void build_table(oracle_ctx *c, int n, int t)
     int m = 0;
     for (int l = 0; l < L; ++l) {
         const double h = c->ptdf[l + L * n];
-        if (h == 0.0) continue;
+        if (fabs(h) < PTDF_NOISE) continue;
         const double f = c->f_prev[l + L * t], F = c->fmax[l];
         beta[m++] = (g * c->avgU[l + L * t] / w2 - f + F) / h;     /* U switches on/off */
         beta[m++] = (-g * c->avgK[l + L * t] / w2 - f - F) / h;    /* K switches on/off */

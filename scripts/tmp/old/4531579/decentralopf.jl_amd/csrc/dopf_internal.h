@@ -1,0 +1,104 @@
+// dopf_internal.h — shared declarations of libdopf_hip (gfx950 only).
+//
+// Layout of everything that lives in HBM (all fp64 unless noted):
+//   P            [t + T*g]      generator output, updated IN PLACE each iteration (the x-update of a
+//                               generator needs only its own previous value), generators sorted by node
+//   D, C, E      [t + T*s]      storage discharge / charge / level, in place, storages sorted by node
+//   dltG, dltS   [t + T*a]      change of the agent's net injection in this iteration (only when L > 0:
+//                               feeds the slack sums sum_a U_a, sum_a K_a)
+//   lam [T], mu/rho [l + L*t]   current duals; *_used = the ones the last solve read
+//   inj [n + N*t], s [T], flow [l + L*t], avgU/avgK [l + L*t], price [n + N*t]
+//                               consensus state of the previous iteration, replicated per GPU
+//   tb_*         per (n,t) breakpoint tables of Psi_{n,t} (only when L > 0)
+//   part_*       per work-item partial sums, reduced in a fixed order (bitwise reproducible)
+//   cons         [N*T | L*T | L*T | 1]  the consensus vector that is all-reduced across ranks
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dopf.h"
+
+namespace dopf {
+
+// one block's share of the agent list: agents [a0, a1) all sit at `node`
+struct Item {
+    int a0, a1, node, pad;
+};
+
+// device-resident status word block (one per context)
+struct Status {
+    int iteration;          // admm.iteration (1-based)
+    int converged;          // Convergence.all
+    int halt;               // converged || iteration > max_iters: every kernel returns at once
+    int iters_total;        // iterations computed since creation
+    unsigned long long solver_fail;
+    unsigned long long dbg_scans, dbg_wave_loops, dbg_events;   // storage kernel statistics (DOPF_STATS builds)
+    unsigned long long dbg_reason[4];                           // DOPF_STATS: no prices / Newton / level / sign
+    unsigned long long resbits[3];   // running max of |dual change| as bit patterns (>= 0 doubles)
+    double res[3];          // lambda / mu / rho residual inf-norms of the last checked iteration
+    double total_cost;
+};
+
+struct DevView {
+    int N, L, T, G, S, M2;          // M2 = 2L
+    int nGenItems, nStoItems;
+    int genTT, genR;                // generator block tiling: TT = min(T, 512) timesteps x R agents
+    int genSkip;                    // pair kernel with row skipping (blocks sweep >= 8 passes of agents)
+    int genTT2, genR2;              // pair kernel (copper plate, even T <= 1024): T/2 double2 columns x R2 agents; 0 = off
+    int sliceDual;                  // per launch: k_reduce stops after the slice sums (level 1) and the one-block dual
+                                    // kernel adds the slices itself (single-GPU iterate path, small consensus state)
+    int reduceRB;                   // reduce blocks per node (two-level fixed-order sum)
+    int fuseAgents;                 // copper plate, even T: generators + storages in one launch (k_agents, 256-thread blocks)
+    int use_warm;                   // storage warm-start kernel runs first; the scan kernel serves its failures
+    int max_iters;
+    double gamma, w_flow, w_prox, eps, mask_thr, invA;
+    // problem (read-only)
+    const double *demand, *ptdf, *fmax;
+    const double *gen_mc, *gen_pmax;
+    const double *sto_mc, *sto_pmax, *sto_emax;
+    const Item *gen_items, *sto_items;
+    const int *node_gen_beg, *node_sto_beg;         // N+1 each: agent ranges per node
+    const int *node_gitem_beg, *node_sitem_beg;     // N+1 each: item ranges per node
+    // primal state
+    double *P, *D, *C, *E, *dltG, *dltS;
+    int *gen_state;                 // per generator: 0 = P all zero, 1 = all at pmax, 2 = mixed (pair kernel's row skipping)
+    // duals and consensus state
+    double *lam, *mu, *rho, *lam_used, *mu_used, *rho_used;
+    double *inj, *s, *flow, *avgU, *avgK, *price;
+    // tables
+    double *tb_beta, *tb_psi, *tb_slope, *tb_psi0;
+    int *tb_m;
+    // partials
+    double *part_ginj, *part_gcost;                 // [item*T + t], [item]
+    double *part_sinj, *part_scost;                 // storage scan kernel, per item
+    double *part_sinj_w, *part_scost_w;             // storage warm-start kernel, per item
+    double *nu_prev;                                // [t + T*s] price of stored energy of the last solve
+    int *nu_valid, *sto_fail, *item_fail;           // [s], [s], [item] (= storages of the item the warm start left over)
+    double *part_U, *part_K;                        // [(n*T + t)*L + l]
+    double *part2, *part2_cost;                     // [(n*RB + rb)*T + t], [rb]
+    int *reduce_ticket;                             // [n]
+    double *cons;
+    Status *st;
+};
+
+// consensus states up to this many (n,t) / (l,t) entries take the one-block dual step
+constexpr size_t kSmallConsensus = 4096;
+
+struct Launch {
+    int stoLPS, stoNCH;
+};
+
+// kernels_agents.hip
+void launch_gen_update(const DevView &v, hipStream_t s);
+void launch_sto_update(const DevView &v, const Launch &lc, hipStream_t s);
+void launch_agents_fused(const DevView &v, const Launch &lc, hipStream_t s);
+bool sto_config_supported(int T, Launch *lc);
+// kernels_consensus.hip
+void launch_tables(const DevView &v, hipStream_t s);
+void launch_slack(const DevView &v, hipStream_t s);
+void launch_reduce(const DevView &v, hipStream_t s);
+void launch_dual(const DevView &v, hipStream_t s);      // consensus -> duals, residuals, prices, status
+void launch_derive(const DevView &v, hipStream_t s, bool from_primal);   // consensus -> inj/s/flow/price (no dual step)
+
+}  // namespace dopf

@@ -1,0 +1,1293 @@
+// kernels_agents.hip — the x-update of every agent (gfx950, wave64, fp64).
+//
+// Replaces optimize_subproblem(::Generator) / optimize_subproblem(::Storage)
+// (reference src/optimization/subproblems.jl:19-207 with add_penalty_terms!,
+// src/optimization/penalty_terms.jl:1-53) — there: one JuMP model build + one Gurobi barrier solve
+// per agent per iteration; here: the slack variables U, K are eliminated in closed form and
+//   generator   P*  = clamp(root of a monotone piecewise-linear function, 0, pmax)      per (g,t)
+//   storage     the state-of-charge QP is solved exactly by the price-threshold recursion
+//               (DESIGN.md "storage kernel"): a group of LPS lanes owns one storage, lanes <-> timesteps,
+//               clamp-add maps are composed with wave shuffles (an associative scan), the scalar
+//               price of each constant-price segment comes from a safeguarded Newton iteration.
+// Both kernels also produce the per-item partial sums of the agents' net injection and cost
+// (the agent loop of Result(...), src/structures/results.jl:72-106) in a fixed order.
+#include "dopf_internal.h"
+
+namespace dopf {
+
+__device__ __forceinline__ double clampd(double v, double lo, double hi)
+{
+    return fmin(fmax(v, lo), hi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// generators
+// ------------------------------------------------------------------------------------------------
+//
+// Block = one Item (agents [a0,a1) at one node). Thread (r, tt): timestep tt (+TT, +2TT, ...) of agents
+// a0 + r, a0 + r + R, ...; with T <= 512 the block sweeps a contiguous range of P (agent-major), so
+// every wave access is a dense 512-byte line set. Algorithmic traffic per update: 8 B read + 8 B write
+// of P per (g,t) + 20 B of parameters per agent (L1-broadcast to the T lanes that share an agent).
+template <bool LINES>
+__global__ __launch_bounds__(512) void k_gen_update(DevView v)
+{
+    if (v.st->halt) return;
+    __shared__ double red[512];
+    const Item it = v.gen_items[blockIdx.x];
+    const int T = v.T, N = v.N, TT = v.genTT, R = v.genR;
+    const int tid = threadIdx.x;
+    const int r = tid / TT, tt = tid - r * TT;
+    const double w = v.w_prox, gam = v.gamma;
+    const double inv = 1.0 / (w + gam);
+    double cost = 0.0;
+
+    for (int tc = 0; tc < T; tc += TT) {
+        const int t = tc + tt;
+        double acc = 0.0;
+        if (r < R && t < T) {
+            if (!LINES) {
+                // copper plate / no line touches this problem: Psi(d) = price + gamma (s + d)
+                const double shift = (v.price[it.node + N * t] + gam * v.s[t]) * inv;
+#pragma unroll 4
+                for (int g = it.a0 + r; g < it.a1; g += R) {
+                    const size_t e = (size_t)g * T + t;
+                    const double mc = v.gen_mc[g], pm = v.gen_pmax[g];
+                    const double p0 = v.P[e];
+                    const double pn = clampd(p0 - (mc * inv + shift), 0.0, pm);
+                    v.P[e] = pn;
+                    acc += pn;
+                    cost += mc * pn;
+                }
+            } else {
+                const size_t at = (size_t)it.node + (size_t)N * t;
+                const int m = v.tb_m[at];
+                const double *beta = v.tb_beta + at * v.M2, *psi = v.tb_psi + at * v.M2;
+                const double *slope = v.tb_slope + at * (v.M2 + 1);
+                const double psi0 = v.tb_psi0[at];
+                for (int g = it.a0 + r; g < it.a1; g += R) {
+                    const size_t e = (size_t)g * T + t;
+                    const double mc = v.gen_mc[g], pm = v.gen_pmax[g];
+                    const double p0 = v.P[e];
+                    double dl;
+                    if (m == 0) {
+                        dl = -(mc + psi0) / (slope[0] + w);
+                    } else {
+                        int lo = 0, hi = m;           // first kink with psi + w beta >= -mc
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (psi[mid] + w * beta[mid] >= -mc) hi = mid; else lo = mid + 1;
+                        }
+                        const int a = lo < m ? lo : m - 1;
+                        dl = beta[a] - (mc + psi[a] + w * beta[a]) / (slope[lo] + w);
+                    }
+                    const double pn = clampd(p0 + dl, 0.0, pm);
+                    v.P[e] = pn;
+                    v.dltG[e] = pn - p0;
+                    acc += pn;
+                    cost += mc * pn;
+                }
+            }
+        }
+        // fixed-order reduction over the R agent lanes that share a timestep
+        red[tid] = acc;
+        __syncthreads();
+        if (r == 0 && t < T) {
+            double sum = 0.0;
+            for (int q = 0; q < R; ++q) sum += red[q * TT + tt];
+            v.part_ginj[(size_t)blockIdx.x * T + t] = sum;
+        }
+        __syncthreads();
+    }
+    red[tid] = cost;
+    __syncthreads();
+    for (int sft = 256; sft > 0; sft >>= 1) {
+        if (tid < sft) red[tid] += red[tid + sft];
+        __syncthreads();
+    }
+    if (tid == 0) v.part_gcost[blockIdx.x] = red[0];
+}
+
+// Copper plate, even T: each thread owns TWO consecutive timesteps of an agent, so every P access is a
+// 16-byte-per-lane double2 (the widest coalesced form), half as many load/store instructions per byte.
+template <int BS>
+__device__ __forceinline__ void gen_pair_body(const DevView &v, const int blk)
+{
+    __shared__ double red[2][BS];
+    const Item it = v.gen_items[blk];
+    const int T = v.T, N = v.N, TT = v.genTT2, R = v.genR2;     // TT = T/2 pair columns
+    const int tid = threadIdx.x;
+    const int r = tid / TT, tt = tid - r * TT;
+    const double w = v.w_prox, gam = v.gamma;
+    const double inv = 1.0 / (w + gam);
+    double cost = 0.0, acc0 = 0.0, acc1 = 0.0;
+    if (r < R) {
+        const int t = 2 * tt;
+        const double sh0 = fma(gam, v.s[t], v.price[it.node + N * t]) * inv;
+        const double sh1 = fma(gam, v.s[t + 1], v.price[it.node + N * (t + 1)]) * inv;
+        double2 *P2 = reinterpret_cast<double2 *>(v.P);
+        const size_t half = (size_t)(T >> 1);
+#pragma unroll 4
+        for (int g = it.a0 + r; g < it.a1; g += R) {
+            const size_t e = (size_t)g * half + tt;
+            const double mc = v.gen_mc[g], pm = v.gen_pmax[g];
+            const double2 p0 = P2[e];
+            double2 pn;
+            // explicit fma: the row-skipping variant below must round exactly like this sweep
+            pn.x = clampd(p0.x - fma(mc, inv, sh0), 0.0, pm);
+            pn.y = clampd(p0.y - fma(mc, inv, sh1), 0.0, pm);
+            P2[e] = pn;
+            acc0 += pn.x; acc1 += pn.y;
+            cost = fma(mc, pn.x + pn.y, cost);
+        }
+    }
+    red[0][tid] = acc0; red[1][tid] = acc1;
+    __syncthreads();
+    if (r == 0 && tt < TT) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int q = 0; q < R; ++q) { s0 += red[0][q * TT + tt]; s1 += red[1][q * TT + tt]; }
+        v.part_ginj[(size_t)blk * T + 2 * tt] = s0;
+        v.part_ginj[(size_t)blk * T + 2 * tt + 1] = s1;
+    }
+    __syncthreads();
+    red[0][tid] = cost;
+    __syncthreads();
+    for (int sft = BS / 2; sft > 0; sft >>= 1) {
+        if (tid < sft) red[0][tid] += red[0][tid + sft];
+        __syncthreads();
+    }
+    if (tid == 0) v.part_gcost[blk] = red[0][0];
+}
+
+__global__ __launch_bounds__(512) void k_gen_update_pair(DevView v)
+{
+    if (v.st->halt) return;
+    gen_pair_body<512>(v, blockIdx.x);
+}
+
+// Row skipping variant (used when a block sweeps many agents, so that its fixed cost is amortised): in a
+// settled dispatch two thirds of the generators sit at 0 or at pmax for ALL timesteps and stay there. A word
+// per generator remembers "all zero" / "all at pmax" / "mixed"; an all-zero row stays all zero iff
+// mc/(w+gamma) + min_t shift_t >= 0, an all-pmax row stays iff mc/(w+gamma) + max_t shift_t <= 0 (the update
+// then clamps every element back onto the same bound), so such a row is neither read nor written — its
+// contribution to the sums is 0 or pmax. Results are identical to the full sweep, bit for bit.
+template <int BS>
+__device__ __forceinline__ void gen_pair_skip_body(const DevView &v, const int blk)
+{
+    __shared__ double red[2][BS];
+    __shared__ int flg[2][BS];
+    const Item it = v.gen_items[blk];
+    const int T = v.T, N = v.N, TT = v.genTT2, R = v.genR2;     // TT = T/2 pair columns
+    const int tid = threadIdx.x;
+    const int r = tid / TT, tt = tid - r * TT;
+    const double w = v.w_prox, gam = v.gamma;
+    const double inv = 1.0 / (w + gam);
+    double cost = 0.0, acc0 = 0.0, acc1 = 0.0;
+    double sh0 = 0.0, sh1 = 0.0;
+    if (r < R) {
+        const int t = 2 * tt;
+        sh0 = fma(gam, v.s[t], v.price[it.node + N * t]) * inv;
+        sh1 = fma(gam, v.s[t + 1], v.price[it.node + N * (t + 1)]) * inv;
+    }
+    // min and max of the shift over the horizon (same for every agent of the item)
+    red[0][tid] = (r == 0 && tt < TT) ? fmin(sh0, sh1) : INFINITY;
+    red[1][tid] = (r == 0 && tt < TT) ? fmax(sh0, sh1) : -INFINITY;
+    flg[0][tid] = 3; flg[1][tid] = 3;
+    __syncthreads();
+    for (int sft = BS / 2; sft > 0; sft >>= 1) {
+        if (tid < sft) { red[0][tid] = fmin(red[0][tid], red[0][tid + sft]); red[1][tid] = fmax(red[1][tid], red[1][tid + sft]); }
+        __syncthreads();
+    }
+    const double smin = red[0][0], smax = red[1][0];
+    __syncthreads();
+
+    double2 *P2 = reinterpret_cast<double2 *>(v.P);
+    const size_t half = (size_t)(T >> 1);
+    const int nPass = (it.a1 - it.a0 + R - 1) / R;
+    for (int p = 0; p < nPass; ++p) {
+        const int g = it.a0 + p * R + r;
+        const bool on = r < R && g < it.a1;
+        bool full = false;
+        if (on) {
+            const double mc = v.gen_mc[g], pm = v.gen_pmax[g];
+            const int stt = v.gen_state[g];                 // 0 all zero, 1 all at pmax, 2 mixed
+            // fma(mc, inv, .) is monotone in its addend, so its extremes over t are at smin / smax
+            if (stt == 0 && fma(mc, inv, smin) >= 0.0) {
+                // stays all zero: nothing to read, write or add
+            } else if (stt == 1 && fma(mc, inv, smax) <= 0.0) {
+                acc0 += pm; acc1 += pm; cost = fma(mc, pm + pm, cost);      // stays all at pmax
+            } else {
+                full = true;
+                const size_t e = (size_t)g * half + tt;
+                const double2 p0 = P2[e];
+                double2 pn;
+                pn.x = clampd(p0.x - fma(mc, inv, sh0), 0.0, pm);
+                pn.y = clampd(p0.y - fma(mc, inv, sh1), 0.0, pm);
+                P2[e] = pn;
+                acc0 += pn.x; acc1 += pn.y;
+                cost = fma(mc, pn.x + pn.y, cost);
+                const int bits = ((pn.x == 0.0 && pn.y == 0.0) ? 1 : 0) | ((pn.x == pm && pn.y == pm) ? 2 : 0);
+                if (bits != 3) atomicAnd(&flg[p & 1][r], bits);
+            }
+        }
+        __syncthreads();
+        if (full && tt == 0) {
+            const int bits = flg[p & 1][r];
+            v.gen_state[g] = (bits & 1) ? 0 : ((bits & 2) ? 1 : 2);
+        }
+        if (tt == 0 && r < R) flg[p & 1][r] = 3;              // free again two passes later
+    }
+    __syncthreads();
+    red[0][tid] = acc0; red[1][tid] = acc1;
+    __syncthreads();
+    if (r == 0 && tt < TT) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int q = 0; q < R; ++q) { s0 += red[0][q * TT + tt]; s1 += red[1][q * TT + tt]; }
+        v.part_ginj[(size_t)blk * T + 2 * tt] = s0;
+        v.part_ginj[(size_t)blk * T + 2 * tt + 1] = s1;
+    }
+    __syncthreads();
+    red[0][tid] = cost;
+    __syncthreads();
+    for (int sft = BS / 2; sft > 0; sft >>= 1) {
+        if (tid < sft) red[0][tid] += red[0][tid + sft];
+        __syncthreads();
+    }
+    if (tid == 0) v.part_gcost[blk] = red[0][0];
+}
+
+__global__ __launch_bounds__(512) void k_gen_update_pair_skip(DevView v)
+{
+    if (v.st->halt) return;
+    gen_pair_skip_body<512>(v, blockIdx.x);
+}
+
+void launch_gen_update(const DevView &v, hipStream_t s)
+{
+    if (v.nGenItems == 0) return;
+    if (v.L > 0) hipLaunchKernelGGL(k_gen_update<true>, dim3(v.nGenItems), dim3(512), 0, s, v);
+    else if (v.genTT2 > 0 && v.genSkip) hipLaunchKernelGGL(k_gen_update_pair_skip, dim3(v.nGenItems), dim3(512), 0, s, v);
+    else if (v.genTT2 > 0) hipLaunchKernelGGL(k_gen_update_pair, dim3(v.nGenItems), dim3(512), 0, s, v);
+    else hipLaunchKernelGGL(k_gen_update<false>, dim3(v.nGenItems), dim3(512), 0, s, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// storages
+// ------------------------------------------------------------------------------------------------
+//
+// A group of LPS lanes owns one storage; lane li owns the NCH CONSECUTIVE timesteps li*NCH .. li*NCH+NCH-1.
+// One "scan" evaluates, for a trial price nu, the whole forward recursion
+//     F_t = clamp(F_{t-1} + x_t(nu), 0, emax),  F_0 = 0
+// as an associative scan of clamp-add maps e -> clamp(e + A, LO, HI): NCH maps are composed inside the
+// lane, the lane composites are scanned across the group with DPP row shifts / row broadcasts (no LDS
+// traffic), and the prefix is applied back inside the lane.
+
+struct Map3 {
+    double A, LO, HI;
+};
+
+__device__ __forceinline__ Map3 compose(const Map3 &p, const Map3 &c)   // p first, then c
+{
+    Map3 r;
+    r.A = p.A + c.A;
+    r.LO = clampd(p.LO + c.A, c.LO, c.HI);
+    r.HI = clampd(p.HI + c.A, c.LO, c.HI);
+    return r;
+}
+
+// lanes whose DPP source is out of range (or whose row is masked off) keep `oldv`
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dppd(double oldv, double src)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(oldv), __double2loint(src), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(oldv), __double2hiint(src), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Map3 dppm(const Map3 &m)
+{
+    Map3 p;
+    p.A = dppd<CTRL, ROW_MASK>(m.A, m.A);
+    p.LO = dppd<CTRL, ROW_MASK>(m.LO, m.LO);
+    p.HI = dppd<CTRL, ROW_MASK>(m.HI, m.HI);
+    return p;
+}
+
+// inclusive scan of the lane composites over the lanes of each group
+template <int LPS>
+__device__ __forceinline__ void scan_maps(Map3 &m, int lane)
+{
+    const int r = lane & ((LPS < 16 ? LPS : 16) - 1);
+    { const Map3 p = dppm<0x111, 0xF>(m); if (r >= 1) m = compose(p, m); }                     // row_shr:1
+    if (LPS >= 4) { const Map3 p = dppm<0x112, 0xF>(m); if (r >= 2) m = compose(p, m); }       // row_shr:2
+    if (LPS >= 8) { const Map3 p = dppm<0x114, 0xF>(m); if (r >= 4) m = compose(p, m); }       // row_shr:4
+    if (LPS >= 16) { const Map3 p = dppm<0x118, 0xF>(m); if (r >= 8) m = compose(p, m); }      // row_shr:8
+    if (LPS >= 32) { const Map3 p = dppm<0x142, 0xA>(m); if (lane & 16) m = compose(p, m); }   // row_bcast:15
+    if (LPS >= 64) { const Map3 p = dppm<0x143, 0xC>(m); if (lane & 32) m = compose(p, m); }   // row_bcast:31
+}
+
+// value of the previous lane of the group (garbage for the group's first lane: caller masks it)
+template <int LPS>
+__device__ __forceinline__ double prev_lane(double x)
+{
+    if (LPS <= 16) return dppd<0x111, 0xF>(x, x);      // row_shr:1
+    return dppd<0x138, 0xF>(x, x);                     // wave_shr:1
+}
+
+template <int LPS>
+__device__ __forceinline__ double group_sum(double x)
+{
+    if (LPS >= 2) x += dppd<0xB1, 0xF>(x, x);          // quad_perm [1,0,3,2]
+    if (LPS >= 4) x += dppd<0x4E, 0xF>(x, x);          // quad_perm [2,3,0,1]
+    if (LPS >= 8) x += dppd<0x141, 0xF>(x, x);         // row_half_mirror
+    if (LPS >= 16) x += dppd<0x140, 0xF>(x, x);        // row_mirror
+    if (LPS >= 32) x += __shfl_xor(x, 16);
+    if (LPS >= 64) x += __shfl_xor(x, 32);
+    return x;
+}
+
+template <int LPS>
+__device__ __forceinline__ double group_min(double x)
+{
+    if (LPS >= 2) x = fmin(x, dppd<0xB1, 0xF>(x, x));
+    if (LPS >= 4) x = fmin(x, dppd<0x4E, 0xF>(x, x));
+    if (LPS >= 8) x = fmin(x, dppd<0x141, 0xF>(x, x));
+    if (LPS >= 16) x = fmin(x, dppd<0x140, 0xF>(x, x));
+    if (LPS >= 32) x = fmin(x, __shfl_xor(x, 16));
+    if (LPS >= 64) x = fmin(x, __shfl_xor(x, 32));
+    return x;
+}
+
+// inclusive prefix sum over the lanes of each group
+template <int LPS>
+__device__ __forceinline__ double scan_sum(double x, int lane)
+{
+    const int r = lane & ((LPS < 16 ? LPS : 16) - 1);
+    { const double p = dppd<0x111, 0xF>(0.0, x); if (r >= 1) x += p; }
+    if (LPS >= 4) { const double p = dppd<0x112, 0xF>(0.0, x); if (r >= 2) x += p; }
+    if (LPS >= 8) { const double p = dppd<0x114, 0xF>(0.0, x); if (r >= 4) x += p; }
+    if (LPS >= 16) { const double p = dppd<0x118, 0xF>(0.0, x); if (r >= 8) x += p; }
+    if (LPS >= 32) { const double p = dppd<0x142, 0xA>(0.0, x); if (lane & 16) x += p; }
+    if (LPS >= 64) { const double p = dppd<0x143, 0xC>(0.0, x); if (lane & 32) x += p; }
+    return x;
+}
+
+template <int LPS>
+__device__ __forceinline__ unsigned long long group_bits(bool pred, int gbase)
+{
+    const unsigned long long b = __ballot(pred);
+    if (LPS == 64) return b;
+    return (b >> gbase) & ((1ull << LPS) - 1ull);
+}
+
+// argmin over [0,pm]^2 of the strictly convex quadratic with gradient (a D - b C - rD, a C - b D - rC),
+// a > b >= 0, given ia = 1/a, idet = 1/(a^2 - b^2); sg = d(C - D)/d(nu) on the active piece
+// (rD falls, rC rises with nu at unit rate): 2/(a+b) with both free, 1/a with one, 0 with none.
+// With C "free" D solves a 1-D convex problem (clamp of its stationary point); if the implied C leaves
+// the box, C sits on that bound (monotone contraction argument).
+__device__ __forceinline__ void box2(double a, double b, double ia, double idet, double s2, double rD,
+                                     double rC, double pm, double &D, double &C, double &sg)
+{
+    const double Df = clampd((a * rD + b * rC) * idet, 0.0, pm);
+    const double Cf = (rC + b * Df) * ia;
+    const double Dlo = clampd(rD * ia, 0.0, pm), Dhi = clampd((rD + b * pm) * ia, 0.0, pm);
+    C = clampd(Cf, 0.0, pm);
+    D = Cf < 0.0 ? Dlo : (Cf > pm ? Dhi : Df);
+    const bool fD = D > 0.0 && D < pm, fC = C > 0.0 && C < pm;
+    sg = (fD && fC) ? s2 : ((fD || fC) ? ia : 0.0);
+}
+
+// breakpoint table of Psi_{n,t} as one lane-timestep sees it
+struct TabRef {
+    const double *beta, *psi, *slope;
+    int m;
+    double psi0;
+};
+
+__device__ __forceinline__ TabRef tab_ref(const DevView &v, int node, int t)
+{
+    const size_t at = (size_t)node + (size_t)v.N * t;
+    TabRef r;
+    r.beta = v.tb_beta + at * v.M2;
+    r.psi = v.tb_psi + at * v.M2;
+    r.slope = v.tb_slope + at * (v.M2 + 1);
+    r.m = v.tb_m[at];
+    r.psi0 = v.tb_psi0[at];
+    return r;
+}
+
+// Psi_{n,t}(dl) from the table (first kink >= dl, then the piece left of it)
+__device__ __forceinline__ double tab_psi_at(const TabRef &tb, double dl)
+{
+    if (tb.m == 0) return tb.psi0 + tb.slope[0] * dl;
+    int lo = 0, hi = tb.m;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (tb.beta[mid] >= dl) hi = mid; else lo = mid + 1;
+    }
+    const int a = lo < tb.m ? lo : tb.m - 1;
+    return tb.psi[a] + tb.slope[lo] * (dl - tb.beta[a]);
+}
+
+// (D, C)(nu) of one storage timestep with lines: find the piece of Psi the solution lies on — first kink
+// whose residual r(beta) = beta - (D(z) - C(z) - q0), z = Psi(beta) + nu, is >= 0 (r is increasing) — then
+// the 2x2 box QP with that piece's slope. `hint` remembers the piece between calls: successive prices are
+// close, so two probes around the hint usually replace the 9 dependent table reads of a full bisection.
+__device__ __forceinline__ void eval_lines(const TabRef &tb, int &hint, double w, double iw, double mc, double pm,
+                                           double D0, double C0, double nu, double &dd, double &cc, double &s1,
+                                           double &psi_cur)
+{
+    const double q0 = D0 - C0;
+    double ab = 0.0, ap = tb.psi0, kap = tb.slope[0];
+    const int m = tb.m;
+    if (m > 0) {
+        auto rneg = [&](int idx) -> bool {
+            const double z = tb.psi[idx] + nu;
+            const double Dz = clampd(D0 - (mc + z) * iw, 0.0, pm), Cz = clampd(C0 - (mc - z) * iw, 0.0, pm);
+            return tb.beta[idx] - (Dz - Cz - q0) < 0.0;
+        };
+        int l2 = hint < 0 ? 0 : (hint > m ? m : hint);
+        const bool okLo = l2 == 0 || rneg(l2 - 1);
+        const bool okHi = l2 == m || !rneg(l2);
+        if (!(okLo && okHi)) {
+            int lo = okLo ? l2 + 1 : 0, hi = okLo ? m : l2 - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (!rneg(mid)) hi = mid; else lo = mid + 1;
+            }
+            l2 = lo;
+        }
+        hint = l2;
+        const int a = l2 < m ? l2 : m - 1;
+        ab = tb.beta[a]; ap = tb.psi[a]; kap = tb.slope[l2];
+    }
+    const double theta = ap - kap * (ab + q0);
+    const double a = w + kap;
+    box2(a, kap, 1.0 / a, 1.0 / (a * a - kap * kap), 2.0 / (a + kap), w * D0 - mc - theta - nu, w * C0 - mc + theta + nu,
+         pm, dd, cc, s1);
+    psi_cur = theta + kap * (dd - cc);       // Psi at the step's current net injection
+}
+
+struct StoAgent {
+    double mc, pm, em;
+};
+
+// `item_fail`: number of storages of this item the warm start left over (block-uniform); < 0 = read it
+template <int LPS, int NCH, bool LINES>
+__device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, int item_fail)
+{
+    constexpr int NG = 256 / LPS;
+    __shared__ double red[NG * LPS * NCH];
+    __shared__ double redc[256];
+    const int tid = threadIdx.x, lane = tid & 63, li = tid & (LPS - 1), grp = tid / LPS;
+    const int gbase = lane & ~(LPS - 1);
+    const Item it = v.sto_items[blk];
+    const int T = v.T, N = v.N;
+    if (item_fail < 0) item_fail = v.item_fail[blk];
+    if (v.use_warm && item_fail == 0) {      // the warm start solved this whole item
+        for (int t = tid; t < T; t += 256) v.part_sinj[(size_t)blk * T + t] = 0.0;
+        if (tid == 0) v.part_scost[blk] = 0.0;
+        return;
+    }
+    const double w = v.w_prox, gam = v.gamma;
+    const double a0 = w + gam, ia0 = 1.0 / a0, idet0 = 1.0 / (a0 * a0 - gam * gam), s20 = 2.0 / (a0 + gam);
+    const int tbase = li * NCH;
+
+    double th0[NCH], accQ[NCH];
+    double accCost = 0.0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int t = tbase + c;
+        accQ[c] = 0.0;
+        th0[c] = (!LINES && t < T) ? v.price[it.node + N * t] + gam * v.s[t] : 0.0;
+    }
+    unsigned long long fails = 0;
+#ifdef DOPF_STATS
+    unsigned long long st_scans = 0, st_loops = 0, st_events = 0;
+#endif
+    const int nRep = (it.a1 - it.a0 + NG - 1) / NG;
+
+    for (int rep = 0; rep < nRep; ++rep) {
+        const int s = it.a0 + rep * NG + grp;
+        const bool live = s < it.a1 && (!v.use_warm || v.sto_fail[s] != 0);
+        StoAgent ag;
+        ag.mc = live ? v.sto_mc[s] : 0.0;
+        ag.pm = live ? v.sto_pmax[s] : 0.0;
+        ag.em = live ? v.sto_emax[s] : 0.0;
+        // rD0/rC0: the nu-independent part of the two gradient offsets (copper plate); D0/C0 otherwise
+        double D0[NCH], C0[NCH], nuf[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int t = tbase + c;
+            const bool ok = live && t < T;
+            const size_t e = (size_t)s * T + t;
+            D0[c] = ok ? v.D[e] : 0.0;
+            C0[c] = ok ? v.C[e] : 0.0;
+            nuf[c] = 0.0;
+        }
+        const double tol = 1e-11 * (1.0 + ag.em);
+
+        // x_t(nu): net charge of timestep (li, c) at price nu
+        int hint[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) hint[c] = 0;
+        const double iw = 1.0 / w;
+        auto eval = [&](int c, double nu, double &dd, double &cc, double &s1, double &pc) {
+            if (!LINES) {
+                const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
+                box2(a0, gam, ia0, idet0, s20, w * D0[c] - ag.mc - theta - nu, w * C0[c] - ag.mc + theta + nu,
+                     ag.pm, dd, cc, s1);
+                pc = theta + gam * (dd - cc);
+            } else {
+                const TabRef tb = tab_ref(v, it.node, tbase + c);
+                eval_lines(tb, hint[c], w, iw, ag.mc, ag.pm, D0[c], C0[c], nu, dd, cc, s1, pc);
+            }
+        };
+
+        // ---- price-threshold recursion, backwards over constant-price segments -------------------
+        double nu = 0.0;
+        int k = live ? T - 1 : -1;      // timesteps 0..k are still open
+        int mode = 0;                   // 0: classify at nu, 1: root search for timestep vv
+        int vv = -1, rit = 0;
+        double target = 0.0, lo = -INFINITY, hi = INFINITY, step = 1.0;
+
+        while (__any(k >= 0)) {
+            const bool active = k >= 0;
+#ifdef DOPF_STATS
+            if (li == 0 && active) ++st_scans;
+            if (lane == 0) ++st_loops;
+#endif
+            // -- one scan at price nu
+            double x[NCH], sg[NCH], Sv[NCH], psc[NCH];
+            Map3 loc;
+            loc.A = 0.0; loc.LO = -INFINITY; loc.HI = INFINITY;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int t = tbase + c;
+                double dd = 0.0, cc = 0.0, s1 = 0.0, pc = 0.0;
+                if (t <= k && t < T) eval(c, nu, dd, cc, s1, pc);
+                x[c] = cc - dd;
+                sg[c] = s1;
+                psc[c] = pc;
+                loc.A += x[c];
+                loc.LO = clampd(loc.LO + x[c], 0.0, ag.em);
+                loc.HI = clampd(loc.HI + x[c], 0.0, ag.em);
+            }
+            Map3 inc = loc;
+            scan_maps<LPS>(inc, lane);
+            Map3 ex;
+            ex.A = prev_lane<LPS>(inc.A); ex.LO = prev_lane<LPS>(inc.LO); ex.HI = prev_lane<LPS>(inc.HI);
+            double e = li == 0 ? 0.0 : clampd(ex.A, ex.LO, ex.HI);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                Sv[c] = e + x[c];
+                e = clampd(Sv[c], 0.0, ag.em);
+            }
+
+            // -- helpers on the scan just made: unclamped level at a timestep, its slope in nu, and
+            //    the way out of a flat piece
+            auto level_at = [&](int idx) -> double {
+                const int lown = idx / NCH, cown = idx - lown * NCH;
+                double sel = 0.0;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+                    if (c == cown) sel = Sv[c];
+                return __shfl(sel, gbase + lown);
+            };
+            // dS_idx/dnu = sum of dx_t/dnu over the run of unclamped steps that ends at idx
+            int jlast = -1;      // last clamped step before idx (set by slope_at)
+            auto slope_at = [&](int idx) -> double {
+                jlast = -1;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int t = tbase + c;
+                    const unsigned long long bts = group_bits<LPS>(t < idx && (Sv[c] <= 0.0 || Sv[c] >= ag.em), gbase);
+                    if (bts) { const int j = (63 - __clzll(bts)) * NCH + c; jlast = j > jlast ? j : jlast; }
+                }
+                double part = 0.0;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int t = tbase + c;
+                    if (t > jlast && t <= idx) part += sg[c];
+                }
+                return group_sum<LPS>(part);
+            };
+            // S_idx is flat at nu: jump just past the nearest kink of the x_t in its run (jlast, idx] in direction dir.
+            // Any trial point is legitimate (the bracket keeps the search safe); this one has the right scale.
+            auto flat_jump = [&](int idx, double dir) -> double {
+                // every step of a flat run has D and C on bounds, so its net injection (hence Psi) does not
+                // move with nu and the four prices at which D or C would leave a bound are closed form
+                double best = INFINITY;                   // distance to the nearest such price ahead
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (tbase + c > idx || tbase + c <= jlast) continue;
+                    const double bD = w * D0[c] - ag.mc - psc[c], bC = ag.mc - w * C0[c] - psc[c], wp = w * ag.pm;
+                    const double cand[4] = {bD, bD - wp, bC, bC + wp};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double d = (cand[q] - nu) * dir;
+                        if (d > 0.0) best = fmin(best, d);
+                    }
+                }
+                best = group_min<LPS>(best);
+                if (best < INFINITY) return nu + dir * (best + 1e-9 * (1.0 + fabs(nu) + best));
+                const double tr = nu + dir * step;
+                step *= 4.0;
+                return tr;
+            };
+
+            bool classify = active && mode == 0;
+            if (active && mode == 1) {
+                const double res = level_at(vv) - target;
+                if (res < 0.0) lo = nu; else hi = nu;
+                bool conv = fabs(res) <= 1e-12 * (1.0 + ag.em) || rit >= 80;
+                double trial = nu;
+                if (!conv) {
+                    const double sl = slope_at(vv);
+                    const bool both = lo > -INFINITY && hi < INFINITY;
+                    if (sl > 0.0) {
+                        double r = __builtin_amdgcn_rcp(sl);
+                        r = r * (2.0 - sl * r);
+                        trial = nu - res * r;
+                    } else {
+                        trial = both ? 0.5 * (lo + hi) : flat_jump(vv, res < 0.0 ? 1.0 : -1.0);
+                    }
+                    const bool forceBis = both && rit >= 6 && (rit & 1);
+                    if (!(trial > lo && trial < hi) || forceBis) {
+                        if (both) trial = 0.5 * (lo + hi);
+                        else { trial = (res < 0.0) ? nu + step : nu - step; step *= 4.0; }
+                    }
+                    if (!(trial > lo && trial < hi)) conv = true;   // bracket is two adjacent doubles
+                }
+                if (conv) {
+                    if (rit >= 80 && fabs(res) > 1e-7 * (1.0 + ag.em) && li == 0) ++fails;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c)
+                        if (tbase + c == vv) nuf[c] = nu;
+                    k = vv - 1;
+                    mode = 0;
+                    classify = k >= 0;
+                } else {
+                    nu = trial;
+                    ++rit;
+                }
+            }
+            if (classify) {
+                // largest open timestep whose unclamped level leaves [0, em] at this price
+                int vnew = -1;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int t = tbase + c;
+                    const unsigned long long bts = group_bits<LPS>(t <= k && t < T && (Sv[c] < -tol || Sv[c] > ag.em + tol), gbase);
+                    if (bts) { const int j = (63 - __clzll(bts)) * NCH + c; vnew = j > vnew ? j : vnew; }
+                }
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int t = tbase + c;
+                    if (t > vnew && t <= k) nuf[c] = nu;
+                }
+                if (vnew < 0) {
+                    k = -1;
+                } else {
+                    const double sv = level_at(vnew), sl = slope_at(vnew);
+                    vv = vnew;
+                    target = sv < 0.0 ? 0.0 : ag.em;
+                    const double res = sv - target;
+                    lo = -INFINITY; hi = INFINITY;
+                    if (res < 0.0) lo = nu; else hi = nu;
+                    step = 1.0 + fabs(nu);
+                    if (sl > 0.0) {
+                        double r = __builtin_amdgcn_rcp(sl);
+                        r = r * (2.0 - sl * r);
+                        nu -= res * r;
+                    } else {
+                        nu = flat_jump(vnew, res < 0.0 ? 1.0 : -1.0);
+                    }
+                    mode = 1;
+                    rit = 0;
+#ifdef DOPF_STATS
+                    if (li == 0) ++st_events;
+#endif
+                }
+            }
+        }
+
+        // ---- final (D, C) at each timestep's price, level E = cumsum(C - D), outputs, partial sums ------
+        double Dn[NCH], Cn[NCH], run = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            double s1;
+            Dn[c] = 0.0; Cn[c] = 0.0;
+            double pcx;
+            if (live && tbase + c < T) eval(c, nuf[c], Dn[c], Cn[c], s1, pcx);
+            run += Cn[c] - Dn[c];
+        }
+        if (live && li == 0) v.nu_valid[s] = 1;
+        const double incl = scan_sum<LPS>(run, lane);
+        const double incl_prev = prev_lane<LPS>(incl);     // DPP: every lane must execute it (no ?: around it)
+        double ev = li == 0 ? 0.0 : incl_prev;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            ev += Cn[c] - Dn[c];
+            if (live && tbase + c < T) {
+                const size_t e = (size_t)s * T + (tbase + c);
+                v.D[e] = Dn[c];
+                v.C[e] = Cn[c];
+                v.E[e] = ev;
+                if (LINES) v.dltS[e] = (Dn[c] - Cn[c]) - (D0[c] - C0[c]);
+                v.nu_prev[e] = nuf[c];
+                accQ[c] += Dn[c] - Cn[c];
+                accCost += ag.mc * (Dn[c] + Cn[c]);
+            }
+        }
+    }
+
+    // fixed-order block reduction of the per-timestep sums over the NG groups
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) red[(grp * LPS + li) * NCH + c] = accQ[c];
+    redc[tid] = accCost;
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int t = tbase + c;
+            if (t < T) {
+                double sum = 0.0;
+                for (int g2 = 0; g2 < NG; ++g2) sum += red[(g2 * LPS + li) * NCH + c];
+                v.part_sinj[(size_t)blk * T + t] = sum;
+            }
+        }
+    }
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if (tid < sft) redc[tid] += redc[tid + sft];
+        __syncthreads();
+    }
+    if (tid == 0) v.part_scost[blk] = redc[0];
+    if (fails) atomicAdd(&v.st->solver_fail, fails);
+#ifdef DOPF_STATS
+    if (st_scans) atomicAdd(&v.st->dbg_scans, st_scans);
+    if (st_loops) atomicAdd(&v.st->dbg_wave_loops, st_loops);
+    if (st_events) atomicAdd(&v.st->dbg_events, st_events);
+#endif
+}
+
+template <int LPS, int NCH, bool LINES>
+__global__ __launch_bounds__(256) void k_sto_update(DevView v)
+{
+    if (v.st->halt) return;
+    sto_cold_body<LPS, NCH, LINES>(v, blockIdx.x, -1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// storages, warm start: re-solve on the previous iteration's structure, accept only with a certificate
+// ------------------------------------------------------------------------------------------------
+//
+// Near convergence the SET of timesteps at which a storage is full or empty does not change from one
+// ADMM iteration to the next. This kernel takes that set from the previous level trajectory, gives every
+// segment between two contacts one price and solves sum_{t in seg} x_t(nu) = level change of the segment
+// for all segments at once (segmented Newton: a segmented scan supplies the sums, LDS hands the new
+// price back to the segment's timesteps), then CHECKS the KKT conditions of the storage QP:
+//   levels within [0, emax]; at a contact at 0 the price may only fall going forward, at emax only rise;
+//   the open last segment has price 0 (nu_{T+1} = 0).
+// The QP is strictly convex in (D, C), so a point that passes is THE minimiser — whatever produced the
+// guess. Storages that fail (structure changed, Newton stalled, no previous prices) are left untouched
+// and flagged for the scan kernel. Cost is independent of the number of contacts.
+
+// inclusive segmented scan of (a, b) over the lanes of each group; f = "a segment starts in this lane"
+template <int LPS>
+__device__ __forceinline__ void seg_scan2(int &f, double &a, double &b, int lane)
+{
+    const int r = lane & ((LPS < 16 ? LPS : 16) - 1);
+#define DOPF_SEG_STEP(CTRL, RM, COND)                                                        \
+    {                                                                                        \
+        const int pf = __builtin_amdgcn_update_dpp(f, f, CTRL, RM, 0xF, false);              \
+        const double pa = dppd<CTRL, RM>(a, a), pb = dppd<CTRL, RM>(b, b);                   \
+        if (COND) { if (!f) { a += pa; b += pb; } f |= pf; }                                 \
+    }
+    DOPF_SEG_STEP(0x111, 0xF, r >= 1)
+    if (LPS >= 4) DOPF_SEG_STEP(0x112, 0xF, r >= 2)
+    if (LPS >= 8) DOPF_SEG_STEP(0x114, 0xF, r >= 4)
+    if (LPS >= 16) DOPF_SEG_STEP(0x118, 0xF, r >= 8)
+    if (LPS >= 32) DOPF_SEG_STEP(0x142, 0xA, lane & 16)
+    if (LPS >= 64) DOPF_SEG_STEP(0x143, 0xC, lane & 32)
+#undef DOPF_SEG_STEP
+}
+
+// same, with (max, min) instead of (+, +): a <- max over the segment so far, b <- min
+template <int LPS>
+__device__ __forceinline__ void seg_scan_maxmin(int &f, double &a, double &b, int lane)
+{
+    const int r = lane & ((LPS < 16 ? LPS : 16) - 1);
+#define DOPF_SEG_STEP(CTRL, RM, COND)                                                        \
+    {                                                                                        \
+        const int pf = __builtin_amdgcn_update_dpp(f, f, CTRL, RM, 0xF, false);              \
+        const double pa = dppd<CTRL, RM>(a, a), pb = dppd<CTRL, RM>(b, b);                   \
+        if (COND) { if (!f) { a = fmax(a, pa); b = fmin(b, pb); } f |= pf; }                 \
+    }
+    DOPF_SEG_STEP(0x111, 0xF, r >= 1)
+    if (LPS >= 4) DOPF_SEG_STEP(0x112, 0xF, r >= 2)
+    if (LPS >= 8) DOPF_SEG_STEP(0x114, 0xF, r >= 4)
+    if (LPS >= 16) DOPF_SEG_STEP(0x118, 0xF, r >= 8)
+    if (LPS >= 32) DOPF_SEG_STEP(0x142, 0xA, lane & 16)
+    if (LPS >= 64) DOPF_SEG_STEP(0x143, 0xC, lane & 32)
+#undef DOPF_SEG_STEP
+}
+
+template <int LPS>
+__device__ __forceinline__ double group_max(double x)
+{
+    if (LPS >= 2) x = fmax(x, dppd<0xB1, 0xF>(x, x));
+    if (LPS >= 4) x = fmax(x, dppd<0x4E, 0xF>(x, x));
+    if (LPS >= 8) x = fmax(x, dppd<0x141, 0xF>(x, x));
+    if (LPS >= 16) x = fmax(x, dppd<0x140, 0xF>(x, x));
+    if (LPS >= 32) x = fmax(x, __shfl_xor(x, 16));
+    if (LPS >= 64) x = fmax(x, __shfl_xor(x, 32));
+    return x;
+}
+
+// suffix (right-to-left) inclusive scan of clamp maps x -> clamp(x, lo, hi) over the lanes of each group:
+// lane l ends up with M_l o M_{l+1} o ... o M_last (the right-most map is applied first)
+template <int LPS>
+__device__ __forceinline__ void scan_clamps_rev(double &lo, double &hi, int lane)
+{
+    constexpr int RL = LPS < 16 ? LPS : 16;
+    const int r = lane & (RL - 1);
+#define DOPF_REV_STEP(CTRL, D)                                                       \
+    {                                                                                \
+        const double glo = dppd<CTRL, 0xF>(lo, lo), ghi = dppd<CTRL, 0xF>(hi, hi);   \
+        if (r + D < RL) { const double nlo = clampd(glo, lo, hi), nhi = clampd(ghi, lo, hi); lo = nlo; hi = nhi; } \
+    }
+    DOPF_REV_STEP(0x101, 1)                     // row_shl:1
+    if (LPS >= 4) DOPF_REV_STEP(0x102, 2)
+    if (LPS >= 8) DOPF_REV_STEP(0x104, 4)
+    if (LPS >= 16) DOPF_REV_STEP(0x108, 8)
+#undef DOPF_REV_STEP
+    if (LPS >= 32) {                            // rows 0, 2 take the whole of the next row (its lane 0)
+        const double glo = __shfl(lo, (lane | 15) + 1), ghi = __shfl(hi, (lane | 15) + 1);
+        if ((lane & 16) == 0) { const double nlo = clampd(glo, lo, hi), nhi = clampd(ghi, lo, hi); lo = nlo; hi = nhi; }
+    }
+    if (LPS >= 64) {                            // rows 0, 1 take rows 2-3 (lane 32)
+        const double glo = __shfl(lo, 32), ghi = __shfl(hi, 32);
+        if ((lane & 32) == 0) { const double nlo = clampd(glo, lo, hi), nhi = clampd(ghi, lo, hi); lo = nlo; hi = nhi; }
+    }
+}
+
+// value of the next lane of the group (garbage for the group's last lane: caller masks it)
+template <int LPS>
+__device__ __forceinline__ double next_lane(double x)
+{
+    if (LPS <= 16) return dppd<0x101, 0xF>(x, x);      // row_shl:1
+    return dppd<0x130, 0xF>(x, x);                     // wave_shl:1
+}
+
+// returns the number of storages of the item left to the scan (block-uniform)
+template <int LPS, int NCH, bool LINES>
+__device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
+{
+    constexpr int NG = 256 / LPS, TP = LPS * NCH;
+    __shared__ double red[NG * TP];          // also nuL during the solve
+    __shared__ double baseL[NG * TP];
+    __shared__ int keyL[NG * TP];
+    __shared__ double redc[256];
+    const int tid = threadIdx.x, lane = tid & 63, li = tid & (LPS - 1), grp = tid / LPS;
+    const Item it = v.sto_items[blk];
+    const int T = v.T, N = v.N;
+    const double w = v.w_prox, gam = v.gamma;
+    const double a0 = w + gam, ia0 = 1.0 / a0, idet0 = 1.0 / (a0 * a0 - gam * gam), s20 = 2.0 / (a0 + gam);
+    const int tbase = li * NCH;
+    double *nuL = red + grp * TP, *base = baseL + grp * TP;
+    int *key = keyL + grp * TP;
+
+    double th0[NCH], accQ[NCH];
+    double accCost = 0.0;
+    int anyFail = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int t = tbase + c;
+        accQ[c] = 0.0;
+        th0[c] = (!LINES && t < T) ? v.price[it.node + N * t] + gam * v.s[t] : 0.0;
+    }
+    const int nRep = (it.a1 - it.a0 + NG - 1) / NG;
+    for (int rep = 0; rep < nRep; ++rep) {
+        const int s = it.a0 + rep * NG + grp;
+        const bool live = s < it.a1;
+        const double mc = live ? v.sto_mc[s] : 0.0, pm = live ? v.sto_pmax[s] : 0.0, em = live ? v.sto_emax[s] : 0.0;
+        bool good = live && v.nu_valid[s] != 0;
+        double D0[NCH], C0[NCH], nuv[NCH];
+        int hint[NCH];
+        const double iw = 1.0 / w;
+        double run = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int t = tbase + c;
+            const bool ok = live && t < T;
+            const size_t e = (size_t)s * T + (ok ? t : 0);
+            D0[c] = ok ? v.D[e] : 0.0;
+            C0[c] = ok ? v.C[e] : 0.0;
+            nuv[c] = ok ? v.nu_prev[e] : 0.0;
+            hint[c] = 0;
+            run += C0[c] - D0[c];
+        }
+        // previous level trajectory -> contacts -> segment ends
+        const double inclE = scan_sum<LPS>(run, lane);
+        const double prevE = prev_lane<LPS>(inclE);
+        double eo = li == 0 ? 0.0 : prevE;
+        const double tolc = 1e-9 * (1.0 + em), tolE = 1e-11 * (1.0 + em), tolr = 1e-12 * (1.0 + em);
+        int kind[NCH];                       // 0 free, 1 empty, 2 full
+        bool isend[NCH];
+        double tgt[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int t = tbase + c;
+            eo += C0[c] - D0[c];
+            kind[c] = t < T ? (eo <= tolc ? 1 : (eo >= em - tolc ? 2 : 0)) : 0;
+            isend[c] = t < T && (kind[c] != 0 || t == T - 1);
+            tgt[c] = kind[c] == 2 ? em : 0.0;
+            key[t] = isend[c] ? t : (t >= T ? T - 1 : 0x3fffffff);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int d = 1; d < TP; d <<= 1) {     // next segment end at or after t (pointer jumping in LDS)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int t = tbase + c;
+                if (t + d < TP) { const int o = key[t + d], m0 = key[t]; key[t] = o < m0 ? o : m0; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        int send[NCH];
+        bool st[NCH];
+        // info of the step before this lane's first step: target level if it is a segment end, else -1
+        const double lastInfo = isend[NCH - 1] ? tgt[NCH - 1] : -1.0;
+        const double plInfo = prev_lane<LPS>(lastInfo);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int t = tbase + c;
+            send[c] = key[t < TP ? t : TP - 1];
+            double pinfo;
+            if (c == 0) pinfo = li == 0 ? 0.0 : plInfo;
+            else pinfo = isend[c - 1] ? tgt[c - 1] : -1.0;
+            st[c] = t < T && pinfo >= 0.0;
+            if (st[c]) base[send[c]] = pinfo;                  // level at which this segment starts
+            if (isend[c]) nuL[t] = kind[c] != 0 ? nuv[c] : 0.0; // one price per segment; open last segment: 0
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) nuv[c] = (tbase + c < T) ? nuL[send[c]] : 0.0;
+
+        // ---- segmented Newton ---------------------------------------------------------------------
+        double Dv[NCH], Cv[NCH], px[NCH], ps[NCH];
+        bool conv = false;
+        for (int itn = 0; itn < 8; ++itn) {
+            double sg[NCH];
+            int f = 0;
+            double rx = 0.0, rs = 0.0;
+            bool seen[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int t = tbase + c;
+                double dd = 0.0, cc = 0.0, s1 = 0.0;
+                if (t < T) {
+                    if (!LINES) {
+                        const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
+                        box2(a0, gam, ia0, idet0, s20, w * D0[c] - mc - theta - nuv[c], w * C0[c] - mc + theta + nuv[c], pm, dd, cc, s1);
+                    } else {
+                        const TabRef tb = tab_ref(v, it.node, t);
+                        double pcx;
+                        eval_lines(tb, hint[c], w, iw, mc, pm, D0[c], C0[c], nuv[c], dd, cc, s1, pcx);
+                    }
+                }
+                Dv[c] = dd; Cv[c] = cc; sg[c] = s1;
+                if (st[c]) { rx = 0.0; rs = 0.0; f = 1; }
+                rx += cc - dd; rs += s1;
+                px[c] = rx; ps[c] = rs;
+                seen[c] = f != 0;
+            }
+            int fl = f;
+            double ax = rx, as = rs;
+            seg_scan2<LPS>(fl, ax, as, lane);
+            double cx = prev_lane<LPS>(ax), cs = prev_lane<LPS>(as);
+            if (li == 0) { cx = 0.0; cs = 0.0; }
+            double worst = 0.0;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int t = tbase + c;
+                if (!seen[c]) { px[c] += cx; ps[c] += cs; }
+                if (isend[c] && kind[c] != 0) {
+                    const double r = base[t] + px[c] - tgt[c];
+                    const double ar = fabs(r);
+                    if (ar > tolr) {
+                        if (ps[c] > 0.0) nuL[t] = nuv[c] - r / ps[c];
+                        else worst = INFINITY;            // flat piece: leave it to the scan kernel
+                    }
+                    worst = fmax(worst, ar);
+                }
+            }
+            worst = group_max<LPS>(worst);
+            if (worst <= tolr) { conv = true; }
+            if (!(worst < INFINITY)) { conv = false; }
+            // every group in the wave runs the same number of rounds (DPP scans need all lanes)
+            if (__all(conv || !(worst < INFINITY) || !good)) break;
+            __builtin_amdgcn_wave_barrier();
+            if (!conv) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+                    if (tbase + c < T) nuv[c] = nuL[send[c]];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#ifdef DOPF_STATS
+        if (live && li == 0 && !good) atomicAdd(&v.st->dbg_reason[0], 1ull);
+        else if (live && li == 0 && !conv) atomicAdd(&v.st->dbg_reason[1], 1ull);
+#endif
+        good = good && conv;
+
+        // ---- certificate: levels inside the band, price jumps have the right sign ----------------------
+        // A contact step that is a segment of its own with zero net charge (the storage idles on a bound)
+        // accepts every price of its dead band [rD0, -rC0]; all other segment prices are points. Prices
+        // are then chosen right to left, nu_e = clamp(nu_next, band_e) starting from nu_{T+1} = 0 — the
+        // choice that satisfies the sign condition at e whenever any does — with one suffix scan of
+        // clamp maps, and the sign conditions are checked on that choice.
+        bool okk = true;
+#ifdef DOPF_STATS
+        bool okLevel = true;
+#endif
+        // Copper plate: a segment whose steps ALL sit on a corner of their (D, C) box (charging or discharging at
+        // full rate, or idle) does not move with its price: every price in the intersection of the steps' corner
+        // intervals is a multiplier of that segment, not just the one Newton happened to stop at. With
+        // grad_D = a D - gam C - (rD0 - nu), grad_C = a C - gam D - (rC0 + nu):
+        //   D = 0: nu >= rD0 + gam C      D = pm: nu <= rD0 - a pm + gam C
+        //   C = 0: nu <= -rC0 - gam D     C = pm: nu >= a pm - gam D - rC0
+        double slo[NCH], shi[NCH];
+        if (!LINES) {
+            int f = 0;
+            double rl = -INFINITY, rh = INFINITY;
+            bool seen[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int t = tbase + c;
+                double lo = -INFINITY, hi = INFINITY;
+                if (t < T) {
+                    const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
+                    const double rD0 = w * D0[c] - mc - theta, rC0 = w * C0[c] - mc + theta;
+                    const double dd = Dv[c], cc = Cv[c];
+                    if (dd <= 0.0) lo = rD0 + gam * cc; else if (dd >= pm) hi = rD0 - a0 * pm + gam * cc;
+                    if (cc <= 0.0) hi = fmin(hi, -rC0 - gam * dd); else if (cc >= pm) lo = fmax(lo, a0 * pm - gam * dd - rC0);
+                }
+                if (st[c]) { rl = -INFINITY; rh = INFINITY; f = 1; }
+                rl = fmax(rl, lo); rh = fmin(rh, hi);
+                slo[c] = rl; shi[c] = rh;
+                seen[c] = f != 0;
+            }
+            int fl = f;
+            double al = rl, ah = rh;
+            seg_scan_maxmin<LPS>(fl, al, ah, lane);
+            double cl = prev_lane<LPS>(al), ch = prev_lane<LPS>(ah);
+            if (li == 0) { cl = -INFINITY; ch = INFINITY; }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+                if (!seen[c]) { slo[c] = fmax(slo[c], cl); shi[c] = fmin(shi[c], ch); }
+        }
+        double Ev[NCH], mlo[NCH], mhi[NCH];
+        // Prices: segment i (ending at contact e_i) may take any nu_i in [mlo, mhi] (a point unless the segment is
+        // flat); an empty contact needs nu_i >= nu_{i+1}, a full one nu_i <= nu_{i+1}, and nu past the horizon is 0.
+        // Right to left, the set of nu_i that can be completed to the right is the interval
+        //   empty: [max(mlo, flo_{i+1}), mhi]      full: [mlo, min(mhi, fhi_{i+1})]      open last segment: {0}
+        // — two chains of clamp maps (one for the lower ends, one for the upper ends), one suffix scan each;
+        // the certificate holds iff no interval is empty.
+        double alo = -INFINITY, ahi = INFINITY, blo = -INFINITY, bhi = INFINITY;      // this lane's composed maps
+#pragma unroll
+        for (int c = NCH - 1; c >= 0; --c) {
+            const int t = tbase + c;
+            mlo[c] = -INFINITY; mhi[c] = INFINITY;
+            Ev[c] = 0.0;
+            if (t < T) {
+                Ev[c] = base[send[c]] + px[c];
+                if (Ev[c] < -tolE || Ev[c] > em + tolE) {
+                    okk = false;
+#ifdef DOPF_STATS
+                    okLevel = false;
+#endif
+                }
+                if (isend[c]) {
+                    mlo[c] = mhi[c] = kind[c] != 0 ? nuv[c] : 0.0;
+                    if (!LINES) {
+                        // flat segment (zero slope at its end = every step on a corner): the whole interval
+                        if (kind[c] != 0 && ps[c] == 0.0 && slo[c] <= shi[c] && nuv[c] >= slo[c] - 1e-9 && nuv[c] <= shi[c] + 1e-9) {
+                            mlo[c] = slo[c]; mhi[c] = shi[c];
+                        }
+                    } else if (kind[c] != 0 && st[c] && base[t] == tgt[c]) {
+                        // idle on a bound: with D = C = 0 the step's net injection is unchanged at q = 0: dlt = -q0
+                        const double q0 = D0[c] - C0[c];
+                        const double theta = tab_psi_at(tab_ref(v, it.node, t), -q0);
+                        const double rD0 = w * D0[c] - mc - theta, rC0 = w * C0[c] - mc + theta;
+                        if (rD0 <= -rC0 && nuv[c] >= rD0 - 1e-9 && nuv[c] <= -rC0 + 1e-9) { mlo[c] = rD0; mhi[c] = -rC0; }
+                    }
+                    // lower-end chain: empty x -> max(mlo, x), full/open x -> mlo; upper-end chain: empty/open x -> mhi, full x -> min(mhi, x)
+                    const double a_lo = mlo[c], a_hi = kind[c] == 1 ? INFINITY : mlo[c];
+                    const double b_lo = kind[c] == 2 ? -INFINITY : mhi[c], b_hi = mhi[c];
+                    const double nal = clampd(alo, a_lo, a_hi), nah = clampd(ahi, a_lo, a_hi);
+                    const double nbl = clampd(blo, b_lo, b_hi), nbh = clampd(bhi, b_lo, b_hi);
+                    alo = nal; ahi = nah; blo = nbl; bhi = nbh;
+                }
+            }
+        }
+        scan_clamps_rev<LPS>(alo, ahi, lane);
+        scan_clamps_rev<LPS>(blo, bhi, lane);
+        // ends of the feasible interval arriving from the right of this lane: (lanes to the right)(0)
+        const double rightA = next_lane<LPS>(clampd(0.0, alo, ahi)), rightB = next_lane<LPS>(clampd(0.0, blo, bhi));
+        double flo = li == LPS - 1 ? 0.0 : rightA, fhi = li == LPS - 1 ? 0.0 : rightB;
+#pragma unroll
+        for (int c = NCH - 1; c >= 0; --c) {
+            const int t = tbase + c;
+            if (t < T && isend[c]) {
+                flo = kind[c] == 1 ? fmax(mlo[c], flo) : mlo[c];
+                fhi = kind[c] == 2 ? fmin(mhi[c], fhi) : mhi[c];
+                if (kind[c] != 0) {
+                    const double tn = 1e-10 * (1.0 + fmin(fabs(flo), fabs(fhi)));
+                    if (flo > fhi + tn) okk = false;
+                    nuv[c] = clampd(nuv[c], flo, fmax(flo, fhi));      // (moves only inside a flat segment's interval)
+                }
+            }
+        }
+#ifdef DOPF_STATS
+        {
+            const bool lv = group_bits<LPS>(!okLevel, lane & ~(LPS - 1)) != 0ull, an = group_bits<LPS>(!okk, lane & ~(LPS - 1)) != 0ull;
+            if (live && li == 0 && good && lv) atomicAdd(&v.st->dbg_reason[2], 1ull);
+            else if (live && li == 0 && good && an) atomicAdd(&v.st->dbg_reason[3], 1ull);
+        }
+#endif
+        good = good && (group_bits<LPS>(!okk, lane & ~(LPS - 1)) == 0ull);
+
+        if (live && li == 0) v.sto_fail[s] = good ? 0 : 1;
+        if (live && !good && li == 0) anyFail += 1;
+        if (good) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int t = tbase + c;
+                if (t < T) {
+                    const size_t e = (size_t)s * T + t;
+                    v.D[e] = Dv[c];
+                    v.C[e] = Cv[c];
+                    v.E[e] = Ev[c];
+                    v.nu_prev[e] = nuv[c];
+                    if (LINES) v.dltS[e] = (Dv[c] - Cv[c]) - (D0[c] - C0[c]);
+                    accQ[c] += Dv[c] - Cv[c];
+                    accCost += mc * (Dv[c] + Cv[c]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // fixed-order block reduction of the per-timestep sums over the NG groups
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) red[(grp * LPS + li) * NCH + c] = accQ[c];
+    redc[tid] = accCost;
+    __shared__ int failCount;
+    if (tid == 0) failCount = 0;
+    __syncthreads();
+    if (anyFail) atomicAdd(&failCount, anyFail);     // integer: order does not matter
+    __syncthreads();
+    const int blockFail = failCount;                 // storages of this item left to the scan kernel
+    if (grp == 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int t = tbase + c;
+            if (t < T) {
+                double sum = 0.0;
+                for (int g2 = 0; g2 < NG; ++g2) sum += red[(g2 * LPS + li) * NCH + c];
+                v.part_sinj_w[(size_t)blk * T + t] = sum;
+            }
+        }
+    }
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if (tid < sft) redc[tid] += redc[tid + sft];
+        __syncthreads();
+    }
+    if (tid == 0) { v.part_scost_w[blk] = redc[0]; v.item_fail[blk] = blockFail; }
+    return blockFail;
+}
+
+template <int LPS, int NCH, bool LINES>
+__global__ __launch_bounds__(256) void k_sto_warm(DevView v)
+{
+    if (v.st->halt) return;
+    sto_warm_body<LPS, NCH, LINES>(v, blockIdx.x);
+}
+
+// All x-updates of one copper-plate iteration in ONE launch: blocks [0, nStoItems) solve storages (warm start,
+// then the scan for what it left over, in the same block), the rest sweep generators. The storage blocks are
+// latency/VALU work, the generator blocks are pure streaming, so sharing the CUs hides one behind the other
+// and two kernel boundaries (~4 us each of fixed cost) disappear. Storage blocks come first: they are the long
+// ones (interleaving the two kinds in dispatch order starts the last storage blocks late and costs 50 %).
+// The launch runs at the storage code's 3 waves/SIMD, which starves the streaming generator blocks once the
+// grid is large, so dopf_create only fuses grids whose storage blocks are all resident from the start.
+template <int LPS, int NCH, bool SKIP>
+__global__ __launch_bounds__(256) void k_agents(DevView v)
+{
+    if (v.st->halt) return;
+    const int nS = v.nStoItems;
+    if ((int)blockIdx.x < nS) {
+        const int left = sto_warm_body<LPS, NCH, false>(v, blockIdx.x);     // ends on a __syncthreads: its sto_fail
+        sto_cold_body<LPS, NCH, false>(v, blockIdx.x, left);                // flags are visible to the block here
+    } else if (SKIP) {
+        gen_pair_skip_body<256>(v, blockIdx.x - nS);
+    } else {
+        gen_pair_body<256>(v, blockIdx.x - nS);
+    }
+}
+
+bool sto_config_supported(int T, Launch *lc)
+{
+    // lane group x consecutive timesteps per lane; 3 timesteps per lane keeps the kernel at 2 waves/SIMD
+    if (T <= 24) { lc->stoLPS = 8; lc->stoNCH = (T + 7) / 8; return true; }
+    if (T <= 48) { lc->stoLPS = 16; lc->stoNCH = 3; return true; }
+    if (T <= 96) { lc->stoLPS = 32; lc->stoNCH = 3; return true; }
+    if (T <= 192) { lc->stoLPS = 64; lc->stoNCH = 3; return true; }
+    if (T <= 384) { lc->stoLPS = 64; lc->stoNCH = 6; return true; }
+    if (T <= 512) { lc->stoLPS = 64; lc->stoNCH = 8; return true; }
+    return false;
+}
+
+template <int LPS, int NCH>
+static void launch_sto_t(const DevView &v, hipStream_t s)
+{
+    if (v.use_warm) {
+        if (v.L > 0) hipLaunchKernelGGL((k_sto_warm<LPS, (NCH <= 3 ? NCH : 3), true>), dim3(v.nStoItems), dim3(256), 0, s, v);
+        else hipLaunchKernelGGL((k_sto_warm<LPS, (NCH <= 3 ? NCH : 3), false>), dim3(v.nStoItems), dim3(256), 0, s, v);
+    }
+    if (v.L > 0) hipLaunchKernelGGL((k_sto_update<LPS, NCH, true>), dim3(v.nStoItems), dim3(256), 0, s, v);
+    else hipLaunchKernelGGL((k_sto_update<LPS, NCH, false>), dim3(v.nStoItems), dim3(256), 0, s, v);
+}
+
+template <int LPS, int NCH>
+static void launch_agents_t(const DevView &v, hipStream_t s)
+{
+    const dim3 grid(v.nStoItems + v.nGenItems);
+    if (v.genSkip) hipLaunchKernelGGL((k_agents<LPS, NCH, true>), grid, dim3(256), 0, s, v);
+    else hipLaunchKernelGGL((k_agents<LPS, NCH, false>), grid, dim3(256), 0, s, v);
+}
+
+void launch_agents_fused(const DevView &v, const Launch &lc, hipStream_t s)
+{
+#define DOPF_CASE(LPS_, NCH_) if (lc.stoLPS == LPS_ && lc.stoNCH == NCH_) { launch_agents_t<LPS_, NCH_>(v, s); return; }
+    DOPF_CASE(8, 1) DOPF_CASE(8, 2) DOPF_CASE(8, 3)
+    DOPF_CASE(16, 3)
+    DOPF_CASE(32, 3)
+    DOPF_CASE(64, 3)
+#undef DOPF_CASE
+}
+
+void launch_sto_update(const DevView &v, const Launch &lc, hipStream_t s)
+{
+    if (v.nStoItems == 0) return;
+#define DOPF_CASE(LPS_, NCH_) if (lc.stoLPS == LPS_ && lc.stoNCH == NCH_) { launch_sto_t<LPS_, NCH_>(v, s); return; }
+    DOPF_CASE(8, 1) DOPF_CASE(8, 2) DOPF_CASE(8, 3)
+    DOPF_CASE(16, 3)
+    DOPF_CASE(32, 3)
+    DOPF_CASE(64, 3) DOPF_CASE(64, 6) DOPF_CASE(64, 8)
+#undef DOPF_CASE
+}
+
+}  // namespace dopf

@@ -1,0 +1,184 @@
+/*
+ * dopf.h — C ABI of libdopf_hip: the MI355X-native ADMM consensus-OPF inner loop.
+ *
+ * This is the drop-in boundary for the hot path of rockstaedt/DecentralOPF.jl
+ * (reference paths are relative to the reference checkout):
+ *
+ *   dopf_create            replaces  ADMM(gamma, nodes, generators, storages, lines)
+ *                                    src/structures/admm.jl:23-62 (state, zero duals, maps)
+ *   dopf_iterate           replaces  run!(admm) / calculate_iteration!(admm)
+ *                                    src/optimization/run.jl:1-16
+ *                                    = optimize_all_subproblems!  src/optimization/subproblems.jl:1-17
+ *                                    + update_duals!              src/optimization/update_duals.jl:1-39
+ *                                    + check_convergence!         src/optimization/convergence.jl:1-31
+ *   dopf_local_update      replaces  optimize_subproblem.(generators|storages)
+ *                                    src/optimization/subproblems.jl:19-207 (+ penalty_terms.jl:1-53)
+ *                                    and the agent sums of Result(...) src/structures/results.jl:50-106
+ *   dopf_apply_consensus   replaces  the rest of Result(...) (avg_U/avg_K, line_utilization,
+ *                                    results.jl:108-116), update_duals! and check_convergence!
+ *   dopf_get_duals         replaces  admm.lambdas[end], admm.mues[end], admm.rhos[end]
+ *   dopf_get_duals_used    replaces  admm.lambdas[admm.iteration] ... (the duals the last solve used;
+ *                                    these feed get_nodal_price(admm.iteration),
+ *                                    src/opf_admm_decentral.jl:9)
+ *   dopf_get_primal        replaces  ResultGenerator.generation / ResultStorage.{discharge,charge,level}
+ *                                    src/structures/results.jl:1-17
+ *   dopf_get_consensus     replaces  Result.{injection,avg_U,avg_K,line_utilization,total_costs}
+ *                                    src/structures/results.jl:37-48
+ *   dopf_get_residuals     replaces  Convergence.{lambda_res,mue_res,rho_res} (inf-norms)
+ *                                    src/structures/convergence.jl:1-20
+ *   dopf_get_nodal_price   replaces  get_nodal_price(iteration) src/helpers/network_elements.jl:16-25
+ *   dopf_set_state         (no reference counterpart: resume / trajectory tests; the reference
+ *                                    keeps whole histories in admm.results / admm.lambdas instead)
+ *
+ * Conventions
+ *   - all matrices are Julia column-major: demand[n + N*t], ptdf[l + L*n], mu[l + L*t];
+ *   - per-agent time series are agent-major: P[t + T*g], D/C/E[t + T*s];
+ *   - node ids are 0-based int32; all reals are double (the reference computes in Float64);
+ *   - every pointer argument is caller-owned HOST memory, copied in or out before return
+ *     (no aliasing of the caller's GC memory after the call returns), except the device
+ *     pointer handed to dopf_bind_consensus (see there);
+ *   - return 0 = ok, negative = error (DOPF_E_*); message via dopf_last_error;
+ *     no exception or longjmp crosses this boundary;
+ *   - a context is driven by one host thread at a time.
+ *
+ * The same signatures, prefixed oracle_ instead of dopf_, are implemented by the CPU oracle
+ * (oracle/dopf_oracle.c). The oracle is test infrastructure, never a fallback of this library.
+ */
+#ifndef DOPF_H
+#define DOPF_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DOPF_OK            0
+#define DOPF_E_INVALID    -1   /* bad argument / inconsistent sizes */
+#define DOPF_E_NOMEM      -2
+#define DOPF_E_DEVICE     -3   /* HIP runtime error (message has the hipError string) */
+#define DOPF_E_UNSUPPORTED -4
+#define DOPF_E_SOLVER     -5   /* an agent sub-problem did not reach its tolerance */
+
+typedef struct dopf_ctx dopf_ctx;
+
+/* One OPF instance (or one rank's shard of it: G and S then count the LOCAL agents,
+ * everything else is the global network). Mirrors the fields ADMM(...) derives from the
+ * Node/Generator/Storage/Line vectors, src/structures/admm.jl:28-60. */
+typedef struct dopf_problem {
+    int32_t N, L, T, G, S;
+    const double  *demand;    /* N x T, [n + N*t]   (Node.demand, promoted Int -> Float64)      */
+    const double  *ptdf;      /* L x N, [l + L*n]   (calculate_ptdf, src/helpers/ptdf.jl:1-41)   */
+    const double  *f_max;     /* L                  (Line.max_capacity)                          */
+    const double  *gen_mc;    /* G                  (Generator.marginal_costs)                   */
+    const double  *gen_pmax;  /* G                  (Generator.max_generation)                   */
+    const int32_t *gen_node;  /* G, 0-based                                                      */
+    const double  *sto_mc;    /* S                  (Storage.marginal_costs)                     */
+    const double  *sto_pmax;  /* S                  (Storage.max_power)                          */
+    const double  *sto_emax;  /* S                  (Storage.max_level)                          */
+    const int32_t *sto_node;  /* S, 0-based                                                      */
+} dopf_problem;
+
+/* The literals of the reference, collected (SURVEY.md section 5 "Config / flags"). */
+typedef struct dopf_params {
+    double  gamma;      /* 0.3   src/opf_admm_decentral.jl:5  (BASELINE.json calls it rho)      */
+    double  w_flow;     /* 10    src/optimization/subproblems.jl:77-78,176-177                  */
+    double  w_prox;     /* 1     (the literal 1/2 in subproblems.jl:81,180-181 is w_prox/2)     */
+    double  eps;        /* 1e-3  src/optimization/convergence.jl:2                              */
+    double  mask_thr;   /* 1e-2  src/optimization/update_duals.jl:24,36                         */
+    int32_t max_iters;  /* cap on admm.iteration; 0 = none (the reference has none, run.jl:2-4)  */
+    int32_t n_agents_global; /* divisor of avg_U/avg_K (results.jl:108-112); 0 = G+S (one shard) */
+    int32_t device;     /* HIP device ordinal; -1 = current device                              */
+    int32_t flags;      /* DOPF_F_* below                                                        */
+    void   *stream;     /* hipStream_t to enqueue on; NULL = a stream the context creates        */
+} dopf_params;
+
+#define DOPF_F_NO_GRAPH   1   /* launch kernels eagerly instead of through a captured hipGraph   */
+#define DOPF_F_OVERLAP_AGENTS 2 /* storage kernel forked onto a side stream so it overlaps the generator
+                                   kernel (default: one stream, kernels back to back — the per-kernel
+                                   durations then mean the same in every tool)                        */
+
+#define DOPF_F_NO_ROW_SKIP   8  /* generators: always sweep every row of P (no skipping of saturated rows)    */
+#define DOPF_F_NO_WARM_START 4  /* storages: always the cold price-threshold scan (no warm-start kernel) */
+#define DOPF_F_NO_FUSE      16  /* copper plate: generator and storage x-updates as separate launches instead
+                                   of the single k_agents launch                                           */
+
+/* Fill q with the reference's defaults (values above). */
+void dopf_default_params(dopf_params *q);
+
+int  dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q);
+void dopf_destroy(dopf_ctx *ctx);
+/* Message of the last error on ctx; with ctx == NULL the last dopf_create error (thread-local). */
+const char *dopf_last_error(const dopf_ctx *ctx);
+
+/* Run up to n_iters ADMM iterations back to back on the device, one host sync at the end.
+ * Stops exactly like check_convergence!: no test at iteration 1; on the converging step the
+ * iteration counter is NOT bumped and later iterations in the same call are no-ops.
+ * iters_done = iterations actually computed in this call; converged = Convergence.all. */
+int dopf_iterate(dopf_ctx *ctx, int32_t n_iters, int32_t *iters_done, int32_t *converged);
+
+/* Sharded form of one iteration (one process per GPU):
+ *   dopf_local_update     x-update of the local agents + local sums -> consensus buffer
+ *   <all-reduce(sum) of the consensus buffer across ranks, done by the caller>
+ *   dopf_apply_consensus  avg_U/avg_K, flows, dual update, residuals, convergence test
+ * Both enqueue on the context's stream and return without synchronising. */
+int dopf_local_update(dopf_ctx *ctx);
+int dopf_apply_consensus(dopf_ctx *ctx);
+/* Number of doubles in the consensus buffer: N*T injections | L*T sum U | L*T sum K | 1 cost. */
+int64_t dopf_consensus_size(const dopf_ctx *ctx);
+/* Device address of the context's own consensus buffer (for RCCL / a zero-copy tensor view). */
+void *dopf_consensus_ptr(dopf_ctx *ctx);
+/* Use caller-owned DEVICE memory (>= dopf_consensus_size doubles) as the consensus buffer,
+ * e.g. the data_ptr of a torch tensor handed to torch.distributed.all_reduce. */
+int dopf_bind_consensus(dopf_ctx *ctx, void *device_ptr);
+/* Host sync of the context's stream + status read-back (iteration, converged). */
+int dopf_sync(dopf_ctx *ctx, int32_t *iteration, int32_t *converged);
+
+int dopf_get_duals(dopf_ctx *ctx, double *lambda /*T*/, double *mu /*L*T*/, double *rho /*L*T*/);
+int dopf_get_duals_used(dopf_ctx *ctx, double *lambda, double *mu, double *rho);
+int dopf_get_primal(dopf_ctx *ctx, double *P /*T*G*/, double *D, double *C, double *E /*T*S*/);
+int dopf_get_consensus(dopf_ctx *ctx, double *injection /*N*T*/, double *avg_U, double *avg_K,
+                       double *line_util /*L*T each*/, double *total_cost /*1*/);
+int dopf_get_residuals(dopf_ctx *ctx, double *lam_res, double *mu_res, double *rho_res,
+                       int32_t *iteration);
+/* which = 0: duals used by the last solve (what the reference's driver script evaluates),
+ * which = 1: duals after the last update. out is N x T, [n + N*t]. */
+int dopf_get_nodal_price(dopf_ctx *ctx, int32_t which, double *out);
+/* Any of P, D, C, avg_U, avg_K, lambda, mu, rho may be NULL (= keep). iteration >= 1 is the
+ * value admm.iteration would have before the next solve; iteration == 1 means "no result yet"
+ * only if all primal pointers are NULL and the state is untouched. */
+int dopf_set_state(dopf_ctx *ctx, const double *P, const double *D, const double *C,
+                   const double *avg_U, const double *avg_K,
+                   const double *lambda, const double *mu, const double *rho, int32_t iteration);
+
+/* Diagnostics: number of storage sub-problems whose inner root search hit its iteration cap
+ * since creation (0 in every healthy run), and a version string. */
+/* Measurement: n_iters iterations launched kernel by kernel (no graph) with a hipEvent pair around
+ * every kernel on the stream it runs on; one host sync at the end. Average milliseconds per launch. */
+typedef struct dopf_timing {
+    double tables_ms, gen_ms, sto_ms, slack_ms, reduce_ms, dual_ms;  /* per-kernel averages; with agents_fused
+                                                                        gen_ms is the ONE x-update launch
+                                                                        (k_agents) and sto_ms an empty pair */
+    double iter_ms;                                                  /* whole iteration, event to event */
+    double empty_ms;    /* an event pair with nothing between: the fixed cost inside every number above */
+    int32_t iters;
+    int32_t agents_fused;   /* 1: generators and storages ran as one launch */
+} dopf_timing;
+int dopf_iterate_timed(dopf_ctx *ctx, int32_t n_iters, dopf_timing *out);
+
+int64_t dopf_solver_failures(dopf_ctx *ctx);
+/* Diagnostics, 9 counters: [0..2] scan-kernel statistics (only in -DDOPF_STATS builds), [3] storages the
+ * warm-start kernel solved in the LAST iteration, [4] storages it left to the scan kernel, [5..8] reasons
+ * (DOPF_STATS builds). */
+int dopf_debug_stats(dopf_ctx *ctx, uint64_t *out9);
+/* Diagnostics (L > 0): the breakpoint table of node n, timestep t that the last x-update used:
+ * beta, psi: 2L doubles (first *m valid, ascending), slope: 2L+1, psi0 = Psi(0). */
+int dopf_debug_table(dopf_ctx *ctx, int32_t n, int32_t t, double *beta, double *psi, double *slope,
+                     double *psi0, int32_t *m);
+const char *dopf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOPF_H */

@@ -1,0 +1,716 @@
+// dopf_api.hip — host side of libdopf_hip: the C ABI of include/dopf.h.
+//
+// One context = one GPU's shard of the agents + a replica of the O((N+L)T) consensus state.
+// An ADMM iteration is a short kernel chain on one stream (with DOPF_F_OVERLAP_AGENTS the storage
+// kernel is forked onto a side stream so that it overlaps the bandwidth-bound generator kernel):
+//   [k_tables] -> k_gen_update -> k_sto_update -> [k_slack] -> k_reduce -> (all-reduce) -> k_dual -> k_price
+// dopf_iterate replays it from a captured hipGraph (UNROLL iterations per graph launch) so that the
+// loop runs without host round trips; convergence is tested on the device and freezes the state.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "dopf_internal.h"
+
+using namespace dopf;
+
+namespace {
+
+constexpr int kUnroll = 16;
+constexpr int kCheckEvery = 512;
+thread_local char g_create_err[512];
+
+}  // namespace
+
+struct dopf_ctx {
+    DevView v{};
+    Launch lc{};
+    dopf_params q{};
+    int device = 0;
+    hipStream_t main = nullptr, side = nullptr;
+    bool own_main = false;
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipGraphExec_t graph1 = nullptr, graphU = nullptr;
+    bool graphs_valid = false;
+    std::vector<void *> allocs;
+    void *own_cons = nullptr;
+    std::vector<int> gen_perm, sto_perm;   // sorted position -> caller's index
+    Status host_st{};
+    char err[512] = {0};
+};
+
+namespace {
+
+int fail(dopf_ctx *c, int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c ? c->err : g_create_err, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail((c), DOPF_E_DEVICE, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <class Tp>
+int dev_alloc(dopf_ctx *c, Tp **out, size_t n, bool zero = true)
+{
+    void *p = nullptr;
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(Tp);
+    HIPCHK(c, hipMalloc(&p, bytes));
+    c->allocs.push_back(p);
+    if (zero) HIPCHK(c, hipMemsetAsync(p, 0, bytes, c->main));
+    *out = (Tp *)p;
+    return DOPF_OK;
+}
+
+template <class Tp>
+int dev_upload(dopf_ctx *c, const Tp **out, const std::vector<Tp> &h)
+{
+    Tp *p = nullptr;
+    int rc = dev_alloc(c, &p, h.size(), false);
+    if (rc) return rc;
+    if (!h.empty()) HIPCHK(c, hipMemcpyAsync(p, h.data(), h.size() * sizeof(Tp), hipMemcpyHostToDevice, c->main));
+    *out = p;
+    return DOPF_OK;
+}
+
+// split the node-sorted agent list into block work items that never cross a node boundary
+void make_items(const std::vector<int> &node_sorted, int N, int chunk, std::vector<Item> &items,
+                std::vector<int> &node_beg, std::vector<int> &node_item_beg)
+{
+    const int A = (int)node_sorted.size();
+    node_beg.assign(N + 1, 0);
+    for (int a = 0; a < A; ++a) node_beg[node_sorted[a] + 1]++;
+    for (int n = 0; n < N; ++n) node_beg[n + 1] += node_beg[n];
+    node_item_beg.assign(N + 1, 0);
+    items.clear();
+    for (int n = 0; n < N; ++n) {
+        node_item_beg[n] = (int)items.size();
+        for (int a = node_beg[n]; a < node_beg[n + 1]; a += chunk)
+            items.push_back(Item{a, std::min(a + chunk, node_beg[n + 1]), n, 0});
+    }
+    node_item_beg[N] = (int)items.size();
+}
+
+// single: the single-GPU dopf_iterate path (nothing reads cons between the reduce and the dual step)
+static bool slice_dual(const DevView &v, bool single)
+{
+    const size_t NT = (size_t)v.N * v.T, LT = (size_t)v.L * v.T;
+    return single && std::max(NT, LT) <= kSmallConsensus && NT <= 256;     // k_dual_price_small: 8 chunks of 32 entries
+}
+
+void enqueue_local(dopf_ctx *c, bool single)
+{
+    DevView v = c->v;
+    v.sliceDual = slice_dual(v, single) ? 1 : 0;
+    launch_tables(v, c->main);
+    const bool fork = v.nGenItems > 0 && v.nStoItems > 0 && (c->q.flags & DOPF_F_OVERLAP_AGENTS);
+    if (v.fuseAgents) {
+        launch_agents_fused(v, c->lc, c->main);
+    } else if (fork) {
+        hipEventRecord(c->evFork, c->main);
+        hipStreamWaitEvent(c->side, c->evFork, 0);
+        launch_sto_update(v, c->lc, c->side);
+        hipEventRecord(c->evJoin, c->side);
+        launch_gen_update(v, c->main);
+        hipStreamWaitEvent(c->main, c->evJoin, 0);
+    } else {
+        launch_gen_update(v, c->main);
+        launch_sto_update(v, c->lc, c->main);
+    }
+    launch_slack(v, c->main);
+    launch_reduce(v, c->main);
+}
+
+void enqueue_apply(dopf_ctx *c, bool single)
+{
+    DevView v = c->v;
+    v.sliceDual = slice_dual(v, single) ? 1 : 0;
+    launch_dual(v, c->main);
+}
+
+void drop_graphs(dopf_ctx *c)
+{
+    if (c->graph1) hipGraphExecDestroy(c->graph1);
+    if (c->graphU) hipGraphExecDestroy(c->graphU);
+    c->graph1 = c->graphU = nullptr;
+    c->graphs_valid = false;
+}
+
+int build_graph(dopf_ctx *c, int iters, hipGraphExec_t *out)
+{
+    hipGraph_t g = nullptr;
+    HIPCHK(c, hipStreamBeginCapture(c->main, hipStreamCaptureModeRelaxed));
+    for (int i = 0; i < iters; ++i) { enqueue_local(c, true); enqueue_apply(c, true); }
+    HIPCHK(c, hipStreamEndCapture(c->main, &g));
+    hipError_t e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) return fail(c, DOPF_E_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    return DOPF_OK;
+}
+
+int read_status(dopf_ctx *c)
+{
+    HIPCHK(c, hipMemcpyAsync(&c->host_st, c->v.st, sizeof(Status), hipMemcpyDeviceToHost, c->main));
+    HIPCHK(c, hipStreamSynchronize(c->main));
+    return DOPF_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { hipGetDevice(&prev); if (dev != prev) hipSetDevice(dev); else prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char *dopf_version(void) { return "libdopf_hip 0.1 (gfx950)"; }
+
+void dopf_default_params(dopf_params *q)
+{
+    if (!q) return;
+    memset(q, 0, sizeof *q);
+    q->gamma = 0.3; q->w_flow = 10.0; q->w_prox = 1.0; q->eps = 1e-3; q->mask_thr = 1e-2;
+    q->device = -1;
+}
+
+const char *dopf_last_error(const dopf_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
+
+int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
+{
+    if (!out || !p || !q) return fail(nullptr, DOPF_E_INVALID, "null argument");
+    *out = nullptr;
+    if (p->N < 1 || p->T < 1 || p->L < 0 || p->G < 0 || p->S < 0)
+        return fail(nullptr, DOPF_E_INVALID, "bad sizes N=%d L=%d T=%d G=%d S=%d", p->N, p->L, p->T, p->G, p->S);
+    if (!(q->gamma > 0) || !(q->w_prox > 0) || !(q->w_flow > 0))
+        return fail(nullptr, DOPF_E_INVALID, "gamma, w_prox, w_flow must be positive");
+    for (int g = 0; g < p->G; ++g)
+        if (p->gen_node[g] < 0 || p->gen_node[g] >= p->N) return fail(nullptr, DOPF_E_INVALID, "gen_node[%d] out of range", g);
+    for (int s = 0; s < p->S; ++s)
+        if (p->sto_node[s] < 0 || p->sto_node[s] >= p->N) return fail(nullptr, DOPF_E_INVALID, "sto_node[%d] out of range", s);
+    if ((int64_t)p->G * p->T > (int64_t)1 << 40) return fail(nullptr, DOPF_E_INVALID, "problem too large");
+    Launch lc{};
+    if (p->S > 0 && !sto_config_supported(p->T, &lc))
+        return fail(nullptr, DOPF_E_UNSUPPORTED, "storage kernel supports T <= 512 (got %d)", p->T);
+    if (2 * p->L > 4096) return fail(nullptr, DOPF_E_UNSUPPORTED, "table kernel supports L <= 2048 (got %d)", p->L);   // 4 * 2L doubles of LDS
+
+    int ndev = 0;
+    hipError_t e0 = hipGetDeviceCount(&ndev);
+    if (e0 != hipSuccess || ndev < 1)
+        return fail(nullptr, DOPF_E_DEVICE, "no HIP device (%s); libdopf_hip has no CPU fallback", hipGetErrorString(e0));
+    int dev = q->device;
+    if (dev < 0) hipGetDevice(&dev);
+    if (dev >= ndev) return fail(nullptr, DOPF_E_INVALID, "device %d of %d", dev, ndev);
+
+    dopf_ctx *c = new (std::nothrow) dopf_ctx;
+    if (!c) return fail(nullptr, DOPF_E_NOMEM, "out of host memory");
+    c->device = dev;
+    c->q = *q;
+    c->lc = lc;
+    DeviceGuard guard(dev);
+    int rc = DOPF_OK;
+    auto bail = [&](int code) { strncpy(g_create_err, c->err, 511); dopf_destroy(c); return code; };
+#define TRY(x) do { rc = (x); if (rc) return bail(rc); } while (0)
+#define HIPTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(c, DOPF_E_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); return bail(DOPF_E_DEVICE); } } while (0)
+
+    if (q->stream) { c->main = (hipStream_t)q->stream; c->own_main = false; }
+    else { HIPTRY(hipStreamCreateWithFlags(&c->main, hipStreamNonBlocking)); c->own_main = true; }
+    HIPTRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIPTRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+    HIPTRY(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
+
+    DevView &v = c->v;
+    const int N = p->N, L = p->L, T = p->T, G = p->G, S = p->S;
+    v.N = N; v.L = L; v.T = T; v.G = G; v.S = S; v.M2 = 2 * L;
+    v.gamma = q->gamma; v.w_flow = q->w_flow; v.w_prox = q->w_prox; v.eps = q->eps; v.mask_thr = q->mask_thr;
+    v.max_iters = q->max_iters;
+    const int A = q->n_agents_global > 0 ? q->n_agents_global : G + S;
+    v.invA = A > 0 ? 1.0 / (double)A : 0.0;
+    v.use_warm = (S > 0 && lc.stoNCH <= 3 && !(q->flags & DOPF_F_NO_WARM_START)) ? 1 : 0;
+    v.genTT = std::min(T, 512);
+    v.genR = 512 / v.genTT;
+    v.genTT2 = (L == 0 && T % 2 == 0 && T / 2 <= 512) ? T / 2 : 0;
+    v.fuseAgents = (v.genTT2 > 0 && v.genTT2 <= 256 && G > 0 && S > 0 && v.use_warm &&
+                    !(q->flags & (DOPF_F_NO_FUSE | DOPF_F_OVERLAP_AGENTS))) ? 1 : 0;
+    if (v.fuseAgents) {
+        // one launch for all agents pays while its fixed cost matters and every storage block is resident from
+        // the start (3 blocks of 256 per CU at the storage code's register count); see k_agents
+        const int ng = 256 / lc.stoLPS;
+        const int sch = (std::max(ng, (S + 2047) / 2048) + ng - 1) / ng * ng;
+        const long long sto_blocks = (S + sch - 1) / sch + N - 1;
+        if (sto_blocks > 3 * 256 || (long long)G * T > (8ll << 20)) v.fuseAgents = 0;
+    }
+    v.genR2 = v.genTT2 ? (v.fuseAgents ? 256 : 512) / v.genTT2 : 0;
+
+    // sort agents by node (stable), remember the permutation
+    c->gen_perm.resize(G);
+    c->sto_perm.resize(S);
+    std::iota(c->gen_perm.begin(), c->gen_perm.end(), 0);
+    std::iota(c->sto_perm.begin(), c->sto_perm.end(), 0);
+    // generators: by node, then by marginal cost — a settled dispatch parks the cheap ones at pmax and the dear
+    // ones at 0, so the rows the generator kernel may skip (and the ones it must stream) become contiguous
+    std::stable_sort(c->gen_perm.begin(), c->gen_perm.end(), [&](int a, int b) {
+        return p->gen_node[a] != p->gen_node[b] ? p->gen_node[a] < p->gen_node[b] : p->gen_mc[a] < p->gen_mc[b];
+    });
+    std::stable_sort(c->sto_perm.begin(), c->sto_perm.end(), [&](int a, int b) { return p->sto_node[a] < p->sto_node[b]; });
+    std::vector<double> gmc(G), gpm(G), smc(S), spm(S), sem(S);
+    std::vector<int> gnode(G), snode(S);
+    for (int i = 0; i < G; ++i) { int a = c->gen_perm[i]; gmc[i] = p->gen_mc[a]; gpm[i] = p->gen_pmax[a]; gnode[i] = p->gen_node[a]; }
+    for (int i = 0; i < S; ++i) { int a = c->sto_perm[i]; smc[i] = p->sto_mc[a]; spm[i] = p->sto_pmax[a]; sem[i] = p->sto_emax[a]; snode[i] = p->sto_node[a]; }
+    for (int i = 0; i < G; ++i) if (!(gpm[i] >= 0)) { fail(c, DOPF_E_INVALID, "negative generator capacity"); return bail(DOPF_E_INVALID); }
+    for (int i = 0; i < S; ++i) if (!(spm[i] >= 0) || !(sem[i] >= 0)) { fail(c, DOPF_E_INVALID, "negative storage capacity"); return bail(DOPF_E_INVALID); }
+
+    std::vector<Item> gitems, sitems;
+    std::vector<int> ngb, nsb, ngib, nsib;
+    {
+        const int R = v.genTT2 ? v.genR2 : v.genR;
+        int chunk = std::max(R, (G + 2047) / 2048);
+        chunk = (chunk + R - 1) / R * R;
+        make_items(gnode, N, chunk, gitems, ngb, ngib);
+        // (on short blocks the skip test costs more than the rows it saves: measured on config1/config2)
+        v.genSkip = (v.genTT2 > 0 && chunk >= 8 * R && !(q->flags & DOPF_F_NO_ROW_SKIP)) ? 1 : 0;
+        const int NG = S > 0 ? 256 / lc.stoLPS : 1;
+        int schunk = std::max(NG, (S + 2047) / 2048);
+        schunk = (schunk + NG - 1) / NG * NG;
+        make_items(snode, N, schunk, sitems, nsb, nsib);
+    }
+    v.nGenItems = (int)gitems.size();
+    v.nStoItems = (int)sitems.size();
+    {
+        // level-1 reduce blocks per node: ~16 items per block, at most 64 (and N*RB blocks in total)
+        int max_items = 1;
+        for (int n = 0; n < N; ++n) max_items = std::max(max_items, (ngib[n + 1] - ngib[n]) + 2 * (nsib[n + 1] - nsib[n]));   // storage items: scan + warm rows
+        v.reduceRB = std::max(1, std::min(64, (max_items + 31) / 32));
+    }
+
+    const size_t NT = (size_t)N * T, LT = (size_t)L * T;
+    TRY(dev_upload(c, &v.demand, std::vector<double>(p->demand, p->demand + NT)));
+    TRY(dev_upload(c, &v.ptdf, std::vector<double>(p->ptdf, p->ptdf + (size_t)L * N)));
+    TRY(dev_upload(c, &v.fmax, std::vector<double>(p->f_max, p->f_max + L)));
+    TRY(dev_upload(c, &v.gen_mc, gmc)); TRY(dev_upload(c, &v.gen_pmax, gpm));
+    TRY(dev_upload(c, &v.sto_mc, smc)); TRY(dev_upload(c, &v.sto_pmax, spm)); TRY(dev_upload(c, &v.sto_emax, sem));
+    TRY(dev_upload(c, &v.gen_items, gitems)); TRY(dev_upload(c, &v.sto_items, sitems));
+    TRY(dev_upload(c, &v.node_gen_beg, ngb)); TRY(dev_upload(c, &v.node_sto_beg, nsb));
+    {
+        // a generator moves by at most pmax per iteration, a storage's net injection D - C by at most 2 pmax
+        std::vector<double> win(N, 0.0);
+        for (int i = 0; i < G; ++i) win[gnode[i]] = std::max(win[gnode[i]], gpm[i]);
+        for (int i = 0; i < S; ++i) win[snode[i]] = std::max(win[snode[i]], 2.0 * spm[i]);
+        for (int n = 0; n < N; ++n) win[n] = win[n] * (1.0 + 1e-9) + 1e-9;
+        TRY(dev_upload(c, &v.node_win, win));
+    }
+    TRY(dev_upload(c, &v.node_gitem_beg, ngib)); TRY(dev_upload(c, &v.node_sitem_beg, nsib));
+    TRY(dev_alloc(c, &v.P, (size_t)G * T));
+    TRY(dev_alloc(c, &v.gen_state, G));            // zero = "all zero", which is what P is now
+    TRY(dev_alloc(c, &v.D, (size_t)S * T)); TRY(dev_alloc(c, &v.C, (size_t)S * T)); TRY(dev_alloc(c, &v.E, (size_t)S * T));
+    if (L > 0) { TRY(dev_alloc(c, &v.dltG, (size_t)G * T)); TRY(dev_alloc(c, &v.dltS, (size_t)S * T)); }
+    TRY(dev_alloc(c, &v.lam, T)); TRY(dev_alloc(c, &v.mu, LT)); TRY(dev_alloc(c, &v.rho, LT));
+    TRY(dev_alloc(c, &v.lam_used, T)); TRY(dev_alloc(c, &v.mu_used, LT)); TRY(dev_alloc(c, &v.rho_used, LT));
+    TRY(dev_alloc(c, &v.inj, NT)); TRY(dev_alloc(c, &v.s, T)); TRY(dev_alloc(c, &v.flow, LT));
+    TRY(dev_alloc(c, &v.avgU, LT)); TRY(dev_alloc(c, &v.avgK, LT)); TRY(dev_alloc(c, &v.price, NT));
+    if (L > 0) {
+        TRY(dev_alloc(c, &v.tb_beta, NT * v.M2)); TRY(dev_alloc(c, &v.tb_psi, NT * v.M2));
+        TRY(dev_alloc(c, &v.tb_slope, NT * (v.M2 + 1))); TRY(dev_alloc(c, &v.tb_psi0, NT));
+        TRY(dev_alloc(c, &v.tb_m, NT));
+        TRY(dev_alloc(c, &v.part_U, NT * L)); TRY(dev_alloc(c, &v.part_K, NT * L));
+    }
+    TRY(dev_alloc(c, &v.part_ginj, (size_t)v.nGenItems * T)); TRY(dev_alloc(c, &v.part_gcost, v.nGenItems));
+    TRY(dev_alloc(c, &v.part_sinj, (size_t)v.nStoItems * T)); TRY(dev_alloc(c, &v.part_scost, v.nStoItems));
+    TRY(dev_alloc(c, &v.part_sinj_w, (size_t)v.nStoItems * T)); TRY(dev_alloc(c, &v.part_scost_w, v.nStoItems));
+    TRY(dev_alloc(c, &v.nu_prev, (size_t)S * T)); TRY(dev_alloc(c, &v.nu_valid, S)); TRY(dev_alloc(c, &v.sto_fail, S));
+    TRY(dev_alloc(c, &v.item_fail, v.nStoItems));
+    TRY(dev_alloc(c, &v.part2, (size_t)N * v.reduceRB * T)); TRY(dev_alloc(c, &v.part2_cost, v.reduceRB));
+    TRY(dev_alloc(c, &v.reduce_ticket, (size_t)N * ((T + 31) / 32)));
+    double *cons = nullptr;
+    TRY(dev_alloc(c, &cons, NT + 2 * LT + 1));
+    c->own_cons = cons;
+    v.cons = cons;
+    TRY(dev_alloc(c, &v.st, 1));
+    Status st0{};
+    st0.iteration = 1;                                      // admm.jl:29
+    HIPTRY(hipMemcpyAsync(v.st, &st0, sizeof st0, hipMemcpyHostToDevice, c->main));
+    // "no result yet" state: zeros everywhere, injection = -demand (helpers/results.jl:14-73)
+    launch_derive(v, c->main, false);     // all-zero primal state: the consensus buffer is already zero
+    HIPTRY(hipGetLastError());
+    HIPTRY(hipStreamSynchronize(c->main));
+    c->host_st = st0;
+#undef TRY
+#undef HIPTRY
+    *out = c;
+    return DOPF_OK;
+}
+
+void dopf_destroy(dopf_ctx *c)
+{
+    if (!c) return;
+    DeviceGuard guard(c->device);
+    if (c->main) hipStreamSynchronize(c->main);
+    if (c->side) hipStreamSynchronize(c->side);
+    drop_graphs(c);
+    for (void *p : c->allocs) hipFree(p);
+    if (c->evFork) hipEventDestroy(c->evFork);
+    if (c->evJoin) hipEventDestroy(c->evJoin);
+    if (c->side) hipStreamDestroy(c->side);
+    if (c->own_main && c->main) hipStreamDestroy(c->main);
+    delete c;
+}
+
+int dopf_iterate(dopf_ctx *c, int32_t n_iters, int32_t *iters_done, int32_t *converged)
+{
+    if (!c || n_iters < 0) return fail(c, DOPF_E_INVALID, "bad argument");
+    DeviceGuard guard(c->device);
+    const int before = c->host_st.iters_total;
+    const bool eager = (c->q.flags & DOPF_F_NO_GRAPH) != 0;
+    if (!eager && !c->graphs_valid) {
+        int rc = build_graph(c, 1, &c->graph1);
+        if (rc) return rc;
+        rc = build_graph(c, kUnroll, &c->graphU);
+        if (rc) return rc;
+        c->graphs_valid = true;
+    }
+    // Enqueue in slices and look at the device status word between slices, so that a converged (or capped)
+    // run stops being fed no-op launches; one sync per kCheckEvery iterations costs nothing measurable.
+    int left = n_iters;
+    while (left > 0) {
+        int slice = std::min(left, kCheckEvery);
+        left -= slice;
+        if (eager) {
+            for (int i = 0; i < slice; ++i) { enqueue_local(c, true); enqueue_apply(c, true); }
+        } else {
+            for (; slice >= kUnroll; slice -= kUnroll) HIPCHK(c, hipGraphLaunch(c->graphU, c->main));
+            for (; slice > 0; --slice) HIPCHK(c, hipGraphLaunch(c->graph1, c->main));
+        }
+        HIPCHK(c, hipGetLastError());
+        const int rc = read_status(c);
+        if (rc) return rc;
+        if (c->host_st.halt) break;
+    }
+    if (n_iters == 0) { const int rc = read_status(c); if (rc) return rc; }
+    if (iters_done) *iters_done = c->host_st.iters_total - before;
+    if (converged) *converged = c->host_st.converged;
+    return DOPF_OK;
+}
+
+int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
+{
+    if (!c || !out || n_iters < 1 || n_iters > 4096) return fail(c, DOPF_E_INVALID, "bad argument");
+    DeviceGuard guard(c->device);
+    DevView v = c->v;
+    v.sliceDual = slice_dual(v, true) ? 1 : 0;
+    enum { E_T0, E_T1, E_G0, E_G1, E_S0, E_S1, E_K0, E_K1, E_R1, E_D1, E_X0, E_X1, E_N };
+    std::vector<hipEvent_t> ev((size_t)n_iters * E_N);
+    for (auto &e : ev) HIPCHK(c, hipEventCreate(&e));
+    const bool fork = v.nGenItems > 0 && v.nStoItems > 0 && (c->q.flags & DOPF_F_OVERLAP_AGENTS);
+    for (int i = 0; i < n_iters; ++i) {
+        hipEvent_t *e = &ev[(size_t)i * E_N];
+        hipEventRecord(e[E_T0], c->main);
+        launch_tables(v, c->main);
+        hipEventRecord(e[E_T1], c->main);
+        hipStream_t ss = fork ? c->side : c->main;
+        if (fork) { hipEventRecord(c->evFork, c->main); hipStreamWaitEvent(c->side, c->evFork, 0); }
+        hipEventRecord(e[E_G0], c->main);
+        if (v.fuseAgents) launch_agents_fused(v, c->lc, c->main);
+        else launch_gen_update(v, c->main);
+        hipEventRecord(e[E_G1], c->main);
+        hipEventRecord(e[E_S0], ss);
+        if (!v.fuseAgents) launch_sto_update(v, c->lc, ss);
+        hipEventRecord(e[E_S1], ss);
+        if (fork) { hipEventRecord(c->evJoin, c->side); hipStreamWaitEvent(c->main, c->evJoin, 0); }
+        hipEventRecord(e[E_K0], c->main);
+        launch_slack(v, c->main);
+        hipEventRecord(e[E_K1], c->main);
+        launch_reduce(v, c->main);
+        hipEventRecord(e[E_R1], c->main);
+        launch_dual(v, c->main);
+        hipEventRecord(e[E_D1], c->main);
+        hipEventRecord(e[E_X0], c->main);
+        hipEventRecord(e[E_X1], c->main);
+    }
+    HIPCHK(c, hipGetLastError());
+    int rc = read_status(c);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->side));
+    memset(out, 0, sizeof *out);
+    auto ms = [&](hipEvent_t a, hipEvent_t b) { float f = 0.f; hipEventElapsedTime(&f, a, b); return (double)f; };
+    for (int i = 0; i < n_iters; ++i) {
+        hipEvent_t *e = &ev[(size_t)i * E_N];
+        out->tables_ms += ms(e[E_T0], e[E_T1]);
+        out->gen_ms += ms(e[E_G0], e[E_G1]);
+        out->sto_ms += ms(e[E_S0], e[E_S1]);
+        out->slack_ms += ms(e[E_K0], e[E_K1]);
+        out->reduce_ms += ms(e[E_K1], e[E_R1]);
+        out->dual_ms += ms(e[E_R1], e[E_D1]);
+        out->iter_ms += ms(e[E_T0], e[E_D1]);
+        out->empty_ms += ms(e[E_X0], e[E_X1]);
+    }
+    const double inv = 1.0 / n_iters;
+    out->tables_ms *= inv; out->gen_ms *= inv; out->sto_ms *= inv; out->slack_ms *= inv;
+    out->reduce_ms *= inv; out->dual_ms *= inv; out->iter_ms *= inv; out->empty_ms *= inv;
+    out->iters = n_iters;
+    out->agents_fused = v.fuseAgents;
+    for (auto &e : ev) hipEventDestroy(e);
+    return DOPF_OK;
+}
+
+int dopf_local_update(dopf_ctx *c)
+{
+    if (!c) return DOPF_E_INVALID;
+    DeviceGuard guard(c->device);
+    enqueue_local(c, false);
+    HIPCHK(c, hipGetLastError());
+    return DOPF_OK;
+}
+
+int dopf_apply_consensus(dopf_ctx *c)
+{
+    if (!c) return DOPF_E_INVALID;
+    DeviceGuard guard(c->device);
+    enqueue_apply(c, false);
+    HIPCHK(c, hipGetLastError());
+    return DOPF_OK;
+}
+
+int64_t dopf_consensus_size(const dopf_ctx *c)
+{
+    return c ? (int64_t)c->v.N * c->v.T + 2 * (int64_t)c->v.L * c->v.T + 1 : 0;
+}
+
+void *dopf_consensus_ptr(dopf_ctx *c) { return c ? (void *)c->v.cons : nullptr; }
+
+int dopf_bind_consensus(dopf_ctx *c, void *device_ptr)
+{
+    if (!c) return DOPF_E_INVALID;
+    DeviceGuard guard(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->main));
+    c->v.cons = device_ptr ? (double *)device_ptr : (double *)c->own_cons;
+    drop_graphs(c);
+    return DOPF_OK;
+}
+
+int dopf_sync(dopf_ctx *c, int32_t *iteration, int32_t *converged)
+{
+    if (!c) return DOPF_E_INVALID;
+    DeviceGuard guard(c->device);
+    int rc = read_status(c);
+    if (rc) return rc;
+    if (iteration) *iteration = c->host_st.iteration;
+    if (converged) *converged = c->host_st.converged;
+    return DOPF_OK;
+}
+
+static int copy_out(dopf_ctx *c, double *dst, const double *src, size_t n)
+{
+    if (!dst || n == 0) return DOPF_OK;
+    HIPCHK(c, hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, c->main));
+    return DOPF_OK;
+}
+
+int dopf_get_duals(dopf_ctx *c, double *lambda, double *mu, double *rho)
+{
+    if (!c) return DOPF_E_INVALID;
+    DeviceGuard guard(c->device);
+    const size_t LT = (size_t)c->v.L * c->v.T;
+    int rc;
+    if ((rc = copy_out(c, lambda, c->v.lam, c->v.T))) return rc;
+    if ((rc = copy_out(c, mu, c->v.mu, LT))) return rc;
+    if ((rc = copy_out(c, rho, c->v.rho, LT))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->main));
+    return DOPF_OK;
+}
+
+int dopf_get_duals_used(dopf_ctx *c, double *lambda, double *mu, double *rho)
+{
+    if (!c) return DOPF_E_INVALID;
+    DeviceGuard guard(c->device);
+    const size_t LT = (size_t)c->v.L * c->v.T;
+    int rc;
+    if ((rc = copy_out(c, lambda, c->v.lam_used, c->v.T))) return rc;
+    if ((rc = copy_out(c, mu, c->v.mu_used, LT))) return rc;
+    if ((rc = copy_out(c, rho, c->v.rho_used, LT))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->main));
+    return DOPF_OK;
+}
+
+// device rows are in node-sorted order; hand them back in the caller's agent order
+static int get_rows(dopf_ctx *c, double *dst, const double *src, const std::vector<int> &perm)
+{
+    if (!dst || perm.empty()) return DOPF_OK;
+    const int T = c->v.T;
+    std::vector<double> tmp((size_t)perm.size() * T);
+    HIPCHK(c, hipMemcpyAsync(tmp.data(), src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, c->main));
+    HIPCHK(c, hipStreamSynchronize(c->main));
+    for (size_t i = 0; i < perm.size(); ++i) memcpy(dst + (size_t)perm[i] * T, tmp.data() + i * T, sizeof(double) * T);
+    return DOPF_OK;
+}
+
+static int set_rows(dopf_ctx *c, double *dst, const double *src, const std::vector<int> &perm)
+{
+    if (!src || perm.empty()) return DOPF_OK;
+    const int T = c->v.T;
+    std::vector<double> tmp((size_t)perm.size() * T);
+    for (size_t i = 0; i < perm.size(); ++i) memcpy(tmp.data() + i * T, src + (size_t)perm[i] * T, sizeof(double) * T);
+    HIPCHK(c, hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, c->main));
+    HIPCHK(c, hipStreamSynchronize(c->main));
+    return DOPF_OK;
+}
+
+int dopf_get_primal(dopf_ctx *c, double *P, double *D, double *C, double *E)
+{
+    if (!c) return DOPF_E_INVALID;
+    DeviceGuard guard(c->device);
+    int rc;
+    if ((rc = get_rows(c, P, c->v.P, c->gen_perm))) return rc;
+    if ((rc = get_rows(c, D, c->v.D, c->sto_perm))) return rc;
+    if ((rc = get_rows(c, C, c->v.C, c->sto_perm))) return rc;
+    if ((rc = get_rows(c, E, c->v.E, c->sto_perm))) return rc;
+    return DOPF_OK;
+}
+
+int dopf_get_consensus(dopf_ctx *c, double *injection, double *avg_U, double *avg_K, double *line_util, double *total_cost)
+{
+    if (!c) return DOPF_E_INVALID;
+    DeviceGuard guard(c->device);
+    const size_t NT = (size_t)c->v.N * c->v.T, LT = (size_t)c->v.L * c->v.T;
+    int rc;
+    if ((rc = copy_out(c, injection, c->v.inj, NT))) return rc;
+    if ((rc = copy_out(c, avg_U, c->v.avgU, LT))) return rc;
+    if ((rc = copy_out(c, avg_K, c->v.avgK, LT))) return rc;
+    if ((rc = copy_out(c, line_util, c->v.flow, LT))) return rc;
+    if ((rc = read_status(c))) return rc;
+    if (total_cost) *total_cost = c->host_st.total_cost;
+    return DOPF_OK;
+}
+
+int dopf_get_residuals(dopf_ctx *c, double *a, double *b, double *r, int32_t *iteration)
+{
+    if (!c) return DOPF_E_INVALID;
+    DeviceGuard guard(c->device);
+    int rc = read_status(c);
+    if (rc) return rc;
+    if (a) *a = c->host_st.res[0];
+    if (b) *b = c->host_st.res[1];
+    if (r) *r = c->host_st.res[2];
+    if (iteration) *iteration = c->host_st.iteration;
+    return DOPF_OK;
+}
+
+int dopf_get_nodal_price(dopf_ctx *c, int32_t which, double *out)
+{
+    if (!c || !out) return DOPF_E_INVALID;
+    const int N = c->v.N, L = c->v.L, T = c->v.T;
+    std::vector<double> lam(T), mu((size_t)L * T), rho((size_t)L * T), ptdf((size_t)L * N);
+    int rc = which ? dopf_get_duals(c, lam.data(), mu.data(), rho.data())
+                   : dopf_get_duals_used(c, lam.data(), mu.data(), rho.data());
+    if (rc) return rc;
+    DeviceGuard guard(c->device);
+    if (L > 0) HIPCHK(c, hipMemcpy(ptdf.data(), c->v.ptdf, ptdf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    // lambda_t + sum_l (mu + rho)[l,t] * ptdf[l,n]   (helpers/network_elements.jl:16-25)
+    for (int t = 0; t < T; ++t)
+        for (int n = 0; n < N; ++n) {
+            double p = lam[t];
+            for (int l = 0; l < L; ++l) p += (mu[l + (size_t)L * t] + rho[l + (size_t)L * t]) * ptdf[l + (size_t)L * n];
+            out[n + (size_t)N * t] = p;
+        }
+    return DOPF_OK;
+}
+
+int dopf_set_state(dopf_ctx *c, const double *P, const double *D, const double *C, const double *avg_U,
+                   const double *avg_K, const double *lambda, const double *mu, const double *rho, int32_t iteration)
+{
+    if (!c || iteration < 1) return fail(c, DOPF_E_INVALID, "bad argument");
+    DeviceGuard guard(c->device);
+    DevView &v = c->v;
+    const size_t LT = (size_t)v.L * v.T;
+    HIPCHK(c, hipStreamSynchronize(c->main));
+    int rc;
+    if ((rc = set_rows(c, v.P, P, c->gen_perm))) return rc;
+    if ((rc = set_rows(c, v.D, D, c->sto_perm))) return rc;
+    if ((rc = set_rows(c, v.C, C, c->sto_perm))) return rc;
+    auto up = [&](double *dst, const double *src, size_t n) -> int {
+        if (!src || n == 0) return DOPF_OK;
+        HIPCHK(c, hipMemcpy(dst, src, n * sizeof(double), hipMemcpyHostToDevice));
+        return DOPF_OK;
+    };
+    if ((rc = up(v.avgU, avg_U, LT))) return rc;
+    if ((rc = up(v.avgK, avg_K, LT))) return rc;
+    if ((rc = up(v.lam, lambda, v.T))) return rc;
+    if ((rc = up(v.mu, mu, LT))) return rc;
+    if ((rc = up(v.rho, rho, LT))) return rc;
+    if (v.S > 0) HIPCHK(c, hipMemset(v.nu_valid, 0, sizeof(int) * v.S));   // stored prices no longer match the state
+    if (v.G > 0 && P) {                                                     // nor do the row summaries of P
+        std::vector<int> mixed(v.G, 2);
+        HIPCHK(c, hipMemcpy(v.gen_state, mixed.data(), sizeof(int) * v.G, hipMemcpyHostToDevice));
+    }
+    Status st{};
+    HIPCHK(c, hipMemcpy(&st, v.st, sizeof st, hipMemcpyDeviceToHost));
+    st.iteration = iteration;
+    st.converged = 0;
+    st.halt = (v.max_iters > 0 && iteration > v.max_iters);
+    st.resbits[0] = st.resbits[1] = st.resbits[2] = 0;
+    HIPCHK(c, hipMemcpy(v.st, &st, sizeof st, hipMemcpyHostToDevice));
+    launch_derive(v, c->main, true);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->main));
+    c->host_st = st;
+    return DOPF_OK;
+}
+
+// diagnostics: the breakpoint table of Psi_{n,t} as the last x-update saw it (L > 0 only)
+int dopf_debug_table(dopf_ctx *c, int32_t n, int32_t t, double *beta, double *psi, double *slope, double *psi0, int32_t *m)
+{
+    if (!c || c->v.L == 0 || n < 0 || n >= c->v.N || t < 0 || t >= c->v.T) return DOPF_E_INVALID;
+    DeviceGuard guard(c->device);
+    const DevView &v = c->v;
+    const size_t at = (size_t)n + (size_t)v.N * t;
+    HIPCHK(c, hipStreamSynchronize(c->main));
+    HIPCHK(c, hipMemcpy(beta, v.tb_beta + at * v.M2, sizeof(double) * v.M2, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(psi, v.tb_psi + at * v.M2, sizeof(double) * v.M2, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(slope, v.tb_slope + at * (v.M2 + 1), sizeof(double) * (v.M2 + 1), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(psi0, v.tb_psi0 + at, sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(m, v.tb_m + at, sizeof(int), hipMemcpyDeviceToHost));
+    return DOPF_OK;
+}
+
+// diagnostics (DOPF_STATS builds): cumulative storage-kernel counters {scans, wave loop trips, events}
+int dopf_debug_stats(dopf_ctx *c, uint64_t *out3 /* 9 values */)
+{
+    if (!c || !out3) return DOPF_E_INVALID;
+    DeviceGuard guard(c->device);
+    int rc = read_status(c);
+    if (rc) return rc;
+    out3[0] = c->host_st.dbg_scans; out3[1] = c->host_st.dbg_wave_loops; out3[2] = c->host_st.dbg_events;
+    {   // warm-start kernel, LAST iteration: storages it solved / left to the scan kernel
+        std::vector<int> f(c->v.nStoItems);
+        if (!f.empty()) HIPCHK(c, hipMemcpy(f.data(), c->v.item_fail, f.size() * sizeof(int), hipMemcpyDeviceToHost));
+        uint64_t nf = 0;
+        for (int x : f) nf += (uint64_t)x;
+        out3[4] = c->v.use_warm ? nf : (uint64_t)c->v.S;
+        out3[3] = (uint64_t)c->v.S - out3[4];
+    }
+    for (int i = 0; i < 4; ++i) out3[5 + i] = c->host_st.dbg_reason[i];
+    return DOPF_OK;
+}
+
+int64_t dopf_solver_failures(dopf_ctx *c)
+{
+    if (!c) return -1;
+    DeviceGuard guard(c->device);
+    if (read_status(c)) return -1;
+    return (int64_t)c->host_st.solver_fail;
+}
+
+}  // extern "C"

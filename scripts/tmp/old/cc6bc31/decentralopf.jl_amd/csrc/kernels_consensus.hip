@@ -1,0 +1,595 @@
+// kernels_consensus.hip — everything between two x-updates (gfx950, fp64).
+//
+//   k_tables   per (n,t): breakpoint table of Psi_{n,t} (only L > 0)                 [DESIGN.md]
+//   k_slack    per (n,t): sum over the node's agents of the closed-form slacks U, K  (only L > 0)
+//              = `result.avg_U += result_unit.U` of Result(...), src/structures/results.jl:83-84
+//   k_reduce   per-item partials -> consensus vector [inj sums | sum U | sum K | cost]
+//              = the agent loop of Result(...), results.jl:72-106, in a fixed summation order
+//   k_dual     injection, avg_U/avg_K, line_utilization (results.jl:108-116); lambda/mu/rho steps with
+//              the slack mask (src/optimization/update_duals.jl:1-39); |dual change| inf-norms
+//   k_price    price[n,t] = lambda_t + sum_l ptdf[l,n] (mu - rho)[l,t] for the next x-update
+//              (src/optimization/subproblems.jl:67-74) and the stop test of check_convergence!
+//              (src/optimization/convergence.jl:1-31)
+//   k_derive_* rebuild the consensus state from a primal state handed in by dopf_set_state
+#include "dopf_internal.h"
+
+namespace dopf {
+
+__device__ __forceinline__ double dmax0(double a) { return a > 0.0 ? a : 0.0; }
+
+// deterministic block sum (256 threads), result broadcast to all threads
+__device__ __forceinline__ double block_sum256(double x, double *sh)
+{
+    const int tid = threadIdx.x;
+    __syncthreads();
+    sh[tid] = x;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// network part of Psi at offset dl for line l of node n (closed-form slacks inside)
+__device__ __forceinline__ double line_term(const DevView &v, int l, int t, double h, double dl)
+{
+    const double w2 = 2.0 * v.w_flow, g = v.gamma;
+    const double f = v.flow[l + v.L * t] + h * dl, F = v.fmax[l];
+    const double U = dmax0((g * v.avgU[l + v.L * t] - w2 * (f - F)) / (w2 + g));
+    const double K = dmax0((g * v.avgK[l + v.L * t] + w2 * (f + F)) / (w2 + g));
+    return w2 * h * ((f + U - F) - (K - f - F));
+}
+
+// ------------------------------------------------------------------------------------------------
+// breakpoint tables (L > 0): one wave per (n,t)
+// ------------------------------------------------------------------------------------------------
+//
+// Psi_{n,t}(dlt) is piecewise linear with up to 2L kinks, but an agent at node n can only move its injection by
+// |dlt| <= W_n (a generator by pmax, a storage by 2 pmax): kinks left of -W_n only add their slope jumps to the
+// slope at the window's left end, kinks right of +W_n are never reached. Typically a handful of the 2L kinks lie
+// inside the window, so the table that the agent kernels search has a handful of entries, and building it is a
+// classification pass + a rank sort of the few survivors instead of a 512-key bitonic sort per (n,t).
+// Psi is anchored at dlt = 0 (direct evaluation) and walked outwards piece by piece, which keeps full precision
+// where the agents' steps live. Every sum has a fixed order (wave butterflies, list order).
+__device__ __forceinline__ double wave_sum64(double x)
+{
+    for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
+    return x;
+}
+
+__global__ __launch_bounds__(64) void k_tables(DevView v)
+{
+    if (v.st->halt) return;
+    extern __shared__ double shm[];
+    const int N = v.N, L = v.L, M2 = v.M2;
+    double *key = shm, *jmp = shm + M2, *skey = shm + 2 * M2, *sslope = shm + 3 * M2;   // sslope: M2 + 1
+    const int lane = threadIdx.x;
+    const size_t at = blockIdx.x;
+    const int n = (int)(at % N), t = (int)(at / N);
+    const double w2 = 2.0 * v.w_flow, g = v.gamma, act = g / (w2 + g);
+    const double W = v.node_win[n];
+
+    // ---- classify the 2L candidate kinks; keep the ones inside [-W, W] in list order
+    double s0part = 0.0, left = 0.0, pz = 0.0;
+    int c = 0;
+    for (int base = 0; base < M2; base += 64) {
+        const int i = base + lane;
+        double kv = INFINITY, jv = 0.0;
+        if (i < M2) {
+            const int l = i >> 1;
+            const double h = v.ptdf[l + L * n];
+            if (h != 0.0) {
+                const double f = v.flow[l + L * t], F = v.fmax[l];
+                const double dj = w2 * h * h * (1.0 - act);
+                if ((i & 1) == 0) {          // U switches: active where h*dlt < ...
+                    kv = (g * v.avgU[l + L * t] / w2 - f + F) / h;
+                    jv = h > 0.0 ? dj : -dj;
+                    s0part += w2 * h * h * (1.0 + act);     // at -inf exactly one of U, K is active
+                    pz += line_term(v, l, t, h, 0.0);       // Psi(0), network part
+                } else {                     // K switches
+                    kv = (-g * v.avgK[l + L * t] / w2 - f - F) / h;
+                    jv = h > 0.0 ? -dj : dj;
+                }
+            }
+        }
+        const bool fin = kv < INFINITY;                      // (also false for NaN)
+        if (fin && kv < -W) left += jv;
+        const bool in = fin && kv >= -W && kv <= W;
+        const unsigned long long mask = __ballot(in);
+        if (in) {
+            const int pos = c + __popcll(mask & ((1ull << lane) - 1ull));
+            key[pos] = kv;
+            jmp[pos] = jv;
+        }
+        c += __popcll(mask);
+    }
+    const double slope_left = g + wave_sum64(s0part) + wave_sum64(left);    // slope just right of -W
+    const double psiZ = v.price[n + N * t] + g * v.s[t] + wave_sum64(pz);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- rank sort (ties by list position), sorted keys and jumps into skey / sslope[1..]
+    for (int e = lane; e < c; e += 64) {
+        const double ke = key[e];
+        int r = 0;
+        for (int k = 0; k < c; ++k) {
+            const double kk = key[k];
+            r += (kk < ke || (kk == ke && k < e)) ? 1 : 0;
+        }
+        skey[r] = ke;
+        sslope[r + 1] = jmp[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- slopes: piece 0 = left of the first kept kink, piece j+1 = (kink j, kink j+1)
+    double *ob = v.tb_beta + at * M2, *op = v.tb_psi + at * M2, *os = v.tb_slope + at * (M2 + 1);
+    int j0 = 0;                                              // number of kept kinks < 0: 0 lies on piece j0
+    for (int k = 0; k < c; ++k) j0 += skey[k] < 0.0 ? 1 : 0;
+    for (int j = lane; j < c; j += 64) {
+        double sl = slope_left;
+        for (int k = 0; k <= j; ++k) sl += sslope[k + 1];
+        key[j] = sl;                                         // (key[] is free now) slope on piece j+1
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- Psi at the kinks, outwards from 0
+    const double slope_j0 = j0 == 0 ? slope_left : key[j0 - 1];
+    for (int j = lane; j < c; j += 64) {
+        double ps;
+        if (j >= j0) {
+            ps = psiZ + slope_j0 * skey[j0];
+            for (int i = j0 + 1; i <= j; ++i) ps += key[i - 1] * (skey[i] - skey[i - 1]);       // slope on piece i = key[i-1]
+        } else {
+            ps = psiZ + slope_j0 * skey[j0 - 1];
+            for (int i = j0 - 2; i >= j; --i) ps -= key[i] * (skey[i + 1] - skey[i]);            // slope on piece i+1 = key[i]
+        }
+        ob[j] = skey[j];
+        op[j] = ps;
+        os[j + 1] = key[j];
+    }
+    if (lane == 0) {
+        os[0] = slope_left;
+        v.tb_m[at] = c;
+        v.tb_psi0[at] = psiZ;
+    }
+}
+
+void launch_tables(const DevView &v, hipStream_t s)
+{
+    if (v.L == 0) return;
+    const size_t shm = (size_t)(4 * v.M2 + 1) * sizeof(double);
+    static bool big_lds = false;
+    if (shm > 64 * 1024 && !big_lds) {     // worst case (every kink inside the window) needs 4 * 2L doubles
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_tables), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        big_lds = true;
+    }
+    hipLaunchKernelGGL(k_tables, dim3(v.N * v.T), dim3(64), shm, s, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// slack sums (L > 0): one block per (n,t), threads <-> lines, agents staged through LDS
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_slack(DevView v)
+{
+    if (v.st->halt) return;
+    __shared__ double dl[256];
+    const int tid = threadIdx.x;
+    const size_t at = blockIdx.x;
+    const int N = v.N, L = v.L, T = v.T;
+    const int n = (int)(at % N), t = (int)(at / N);
+    const int gb = v.node_gen_beg[n], ng = v.node_gen_beg[n + 1] - gb;
+    const int sb = v.node_sto_beg[n], ns = v.node_sto_beg[n + 1] - sb;
+    const int na = ng + ns;
+    const double w2 = 2.0 * v.w_flow, g = v.gamma, inv = 1.0 / (w2 + g);
+    for (int lc = 0; lc < L; lc += 256) {
+        const int l = lc + tid;
+        double aU = 0.0, aK = 0.0, kap = 0.0, sU = 0.0, sK = 0.0;
+        if (l < L) {
+            const double h = v.ptdf[l + L * n], f = v.flow[l + L * t], F = v.fmax[l];
+            aU = (g * v.avgU[l + L * t] - w2 * (f - F)) * inv;
+            aK = (g * v.avgK[l + L * t] + w2 * (f + F)) * inv;
+            kap = w2 * h * inv;
+        }
+        for (int base = 0; base < na; base += 256) {
+            const int a = base + tid;
+            __syncthreads();
+            if (a < na) dl[tid] = a < ng ? v.dltG[(size_t)(gb + a) * T + t] : v.dltS[(size_t)(sb + a - ng) * T + t];
+            __syncthreads();
+            const int cnt = na - base < 256 ? na - base : 256;
+            if (l < L)
+                for (int j = 0; j < cnt; ++j) {
+                    const double d = dl[j];
+                    sU += dmax0(aU - kap * d);
+                    sK += dmax0(aK + kap * d);
+                }
+        }
+        if (l < L) {
+            v.part_U[at * L + l] = sU;
+            v.part_K[at * L + l] = sK;
+        }
+    }
+}
+
+void launch_slack(const DevView &v, hipStream_t s)
+{
+    if (v.L == 0) return;
+    hipLaunchKernelGGL(k_slack, dim3(v.N * v.T), dim3(256), 0, s, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// reduce: RB blocks per node sum slices of the node's item partials (level 1); the block that
+// finishes last for a node adds the RB slice sums in slice order (level 2) — the order of every
+// addition is fixed, so the result is bitwise reproducible whichever block happens to be last.
+// Remaining blocks sum part_U / part_K over nodes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_reduce(DevView v)
+{
+    if (v.st->halt) return;
+    __shared__ double red[256];
+    __shared__ int last_sh;
+    const int tid = threadIdx.x;
+    const int N = v.N, L = v.L, T = v.T, RB = v.reduceRB;
+    constexpr int TT = 32, R = 8;                       // block = 8 item lanes x 32 timesteps
+    const int TC = (T + TT - 1) / TT;
+    if ((int)blockIdx.x < N * RB * TC) {
+        const int tcx = blockIdx.x % TC, nrb = blockIdx.x / TC;
+        const int n = nrb / RB, rb = nrb - n * RB;
+        const int r = tid >> 5, tt = tid & 31, t = tcx * TT + tt;
+        const int g0 = v.node_gitem_beg[n], ngi = v.node_gitem_beg[n + 1] - g0;
+        const int s0 = v.node_sitem_beg[n], nsi = v.node_sitem_beg[n + 1] - s0;
+        // rows to add: generator items, then the storage items' scan partials, then their warm-start partials
+        const int ni = ngi + 2 * nsi;
+        const int per = (ni + RB - 1) / RB;
+        const int i0 = rb * per, i1 = min(ni, i0 + per);
+        double acc = 0.0;
+        if (t < T) {
+            // four loads in flight per lane, no branch between them (one select on the address); fixed grouping
+            for (int i = i0 + r; i < i1; i += 4 * R) {
+                double x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = i + u * R;
+                    const int jj = j < i1 ? j : i0;                               // in range: always a valid row
+                    const double *row = jj < ngi ? v.part_ginj + (size_t)(g0 + jj) * T
+                                      : (jj < ngi + nsi ? v.part_sinj + (size_t)(s0 + jj - ngi) * T
+                                                        : v.part_sinj_w + (size_t)(s0 + jj - ngi - nsi) * T);
+                    const double val = row[t];
+                    x[u] = j < i1 ? val : 0.0;
+                }
+                acc += (x[0] + x[1]) + (x[2] + x[3]);
+            }
+        }
+        red[tid] = acc;
+        __syncthreads();
+        if (r == 0 && t < T) {
+            double sum = 0.0;
+            for (int q = 0; q < R; ++q) sum += red[q * TT + tt];
+            v.part2[((size_t)n * RB + rb) * T + t] = sum;
+        }
+        // cost partials ride with the first node's slices of the first timestep chunk
+        if (n == 0 && tcx == 0) {
+            const int nc = v.nGenItems + v.nStoItems, cper = (nc + RB - 1) / RB;
+            const int c0 = rb * cper, c1 = min(nc, c0 + cper);
+            double c = 0.0;
+            for (int i = c0 + tid; i < c1; i += 256)
+                c += i < v.nGenItems ? v.part_gcost[i] : v.part_scost[i - v.nGenItems] + v.part_scost_w[i - v.nGenItems];
+            c = block_sum256(c, red);
+            if (tid == 0) v.part2_cost[rb] = c;
+        }
+        if (v.sliceDual) return;        // the dual kernel adds the slices (and the cost slices) itself
+        // publish, take a ticket; the last block of this (node, timestep chunk) finishes the sum.
+        // Hand-off per cdna_hip_programming.md G16: every storing wave drains its stores, the block meets,
+        // ONE lane releases at agent scope and takes the ticket; the last block's lane acquires, the block
+        // meets again, then everybody reads the other blocks' slices with plain loads.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int last = atomicAdd(&v.reduce_ticket[n * TC + tcx], 1) == RB - 1;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            last_sh = last;
+        }
+        __syncthreads();
+        if (last_sh) {
+            // 8 lanes per timestep take interleaved slices; combined in a fixed order
+            double sum = 0.0;
+            if (t < T) {
+                double x[8];                              // RB <= 64: all of this lane's slices in flight at once
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int q = r + R * k;
+                    x[k] = q < RB ? v.part2[((size_t)n * RB + q) * T + t] : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sum += x[k];
+            }
+            __syncthreads();
+            red[tid] = sum;
+            __syncthreads();
+            if (r == 0 && t < T) {
+                double tot = 0.0;
+                for (int q = 0; q < R; ++q) tot += red[q * TT + tt];
+                v.cons[n + (size_t)N * t] = tot;
+            }
+            if (n == 0 && tcx == 0 && tid < 64) {          // cost slices: side by side in wave 0, butterfly sum
+                double c = tid < RB ? v.part2_cost[tid] : 0.0;
+                for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+                if (tid == 0) v.cons[(size_t)N * T + 2 * (size_t)L * T] = c;
+            }
+            if (tid == 0) v.reduce_ticket[n * TC + tcx] = 0;       // ready for the next iteration
+        }
+    } else {
+        const size_t LT = (size_t)L * T;
+        const size_t idx = (size_t)(blockIdx.x - N * RB * TC) * 256 + tid;
+        if (idx < 2 * LT) {
+            const int which = idx >= LT;
+            const size_t rem = idx - which * LT;            // l + L*t
+            const int l = (int)(rem % L), t = (int)(rem / L);
+            const double *src = which ? v.part_K : v.part_U;
+            double sum = 0.0;
+            for (int n = 0; n < N; ++n) sum += src[((size_t)n + (size_t)N * t) * L + l];
+            v.cons[(size_t)N * T + idx] = sum;
+        }
+    }
+}
+
+void launch_reduce(const DevView &v, hipStream_t s)
+{
+    const size_t LT2 = 2 * (size_t)v.L * v.T;
+    const int TC = (v.T + 31) / 32;
+    const int blocks = v.N * v.reduceRB * TC + (int)((LT2 + 255) / 256);
+    hipLaunchKernelGGL(k_reduce, dim3(blocks), dim3(256), 0, s, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dual update
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_max_pos(unsigned long long *addr, double vpos)
+{
+    atomicMax(addr, (unsigned long long)__double_as_longlong(vpos));   // vpos >= 0: bit order = value order
+}
+
+// element i of the dual step: injection / imbalance / flows from the consensus vector, then the
+// lambda (i < T) and mu, rho (i < L*T) ascent steps; returns this element's |dual change|
+template <bool UPDATE>
+__device__ __forceinline__ void dual_body(const DevView &v, size_t i, double &rl, double &rm, double &rr)
+{
+    const int N = v.N, L = v.L, T = v.T;
+    const size_t NT = (size_t)N * T, LT = (size_t)L * T;
+    const double *cinj = v.cons, *cU = v.cons + NT, *cK = cU + LT;
+    if (i < NT) v.inj[i] = cinj[i] - v.demand[i];                         // results.jl:58-100
+    if (i < (size_t)T) {
+        const int t = (int)i;
+        double sum = 0.0;
+        for (int n = 0; n < N; ++n) sum += cinj[n + (size_t)N * t] - v.demand[n + (size_t)N * t];
+        v.s[t] = sum;
+        if (UPDATE) {
+            const double lo = v.lam[t], ln = lo + v.gamma * sum;          // update_duals.jl:8-13
+            v.lam_used[t] = lo;
+            v.lam[t] = ln;
+            rl = fmax(rl, fabs(ln - lo));
+        }
+    }
+    if (i < LT) {
+        const int l = (int)(i % L), t = (int)(i / L);
+        double f = 0.0;
+        for (int n = 0; n < N; ++n) f += v.ptdf[l + (size_t)L * n] * (cinj[n + (size_t)N * t] - v.demand[n + (size_t)N * t]);
+        v.flow[i] = f;                                                    // results.jl:114
+        if (UPDATE) {
+            const double aU = v.invA * cU[i], aK = v.invA * cK[i];       // results.jl:108-112
+            v.avgU[i] = aU;
+            v.avgK[i] = aK;
+            const double mo = v.mu[i], ro = v.rho[i], F = v.fmax[l];
+            const double mn = (mo + v.gamma * (f + aU - F)) * (aU <= v.mask_thr ? 1.0 : 0.0);   // :18-25
+            const double rn = (ro + v.gamma * (aK - f - F)) * (aK <= v.mask_thr ? 1.0 : 0.0);   // :30-37
+            v.mu_used[i] = mo; v.rho_used[i] = ro;
+            v.mu[i] = mn; v.rho[i] = rn;
+            rm = fmax(rm, fabs(mn - mo));
+            rr = fmax(rr, fabs(rn - ro));
+        }
+    }
+}
+
+// price[n,t] = lambda_t + sum_l ptdf[l,n] (mu - rho)[l,t]   (subproblems.jl:67-74), element i = n + N*t
+__device__ __forceinline__ void price_body(const DevView &v, size_t i)
+{
+    const int N = v.N, L = v.L;
+    const int n = (int)(i % N), t = (int)(i / N);
+    double p = v.lam[t];
+    for (int l = 0; l < L; ++l) p += v.ptdf[l + (size_t)L * n] * (v.mu[l + (size_t)L * t] - v.rho[l + (size_t)L * t]);
+    v.price[i] = p;
+}
+
+// check_convergence!, convergence.jl:1-31 (one thread)
+__device__ __forceinline__ void status_update(const DevView &v, double r0, double r1, double r2)
+{
+    Status *st = v.st;
+    if (st->iteration != 1) {                                             // convergence.jl:3
+        st->res[0] = r0; st->res[1] = r1; st->res[2] = r2;
+        st->converged = (r0 < v.eps) && (r1 < v.eps) && (r2 < v.eps);
+    }
+    st->iters_total += 1;
+    if (!st->converged) st->iteration += 1;                               // convergence.jl:25-30
+    st->halt = st->converged || (v.max_iters > 0 && st->iteration > v.max_iters);
+}
+
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void k_dual(DevView v)
+{
+    if (UPDATE && v.st->halt) return;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    double rl = 0.0, rm = 0.0, rr = 0.0;
+    dual_body<UPDATE>(v, i, rl, rm, rr);
+    if (UPDATE) {
+        // wave max, then one atomic per wave (max is order independent: deterministic)
+        for (int d = 32; d > 0; d >>= 1) {
+            rl = fmax(rl, __shfl_xor(rl, d));
+            rm = fmax(rm, __shfl_xor(rm, d));
+            rr = fmax(rr, __shfl_xor(rr, d));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (rl > 0.0) atomic_max_pos(&v.st->resbits[0], rl);
+            if (rm > 0.0) atomic_max_pos(&v.st->resbits[1], rm);
+            if (rr > 0.0) atomic_max_pos(&v.st->resbits[2], rr);
+        }
+        if (i == 0) v.st->total_cost = v.cons[(size_t)v.N * v.T + 2 * (size_t)v.L * v.T];
+    }
+}
+
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void k_price(DevView v)
+{
+    const size_t NT = (size_t)v.N * v.T;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // recomputed even after a halt: the duals are frozen then, so the values are identical
+    if (i < NT) price_body(v, i);
+    if (UPDATE && i == 0) {
+        Status *st = v.st;
+        if (st->halt) return;
+        const double r0 = __longlong_as_double((long long)st->resbits[0]);
+        const double r1 = __longlong_as_double((long long)st->resbits[1]);
+        const double r2 = __longlong_as_double((long long)st->resbits[2]);
+        st->resbits[0] = st->resbits[1] = st->resbits[2] = 0ull;
+        status_update(v, r0, r1, r2);
+    }
+}
+
+// dual step + prices + stop test in ONE block when the consensus state is small (every copper-plate case):
+// saves a launch per iteration, which is what the small configurations are bound by
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void k_dual_price_small(DevView v)
+{
+    if (UPDATE && v.st->halt) return;
+    __shared__ double red[8][256];
+    const int tid = threadIdx.x;
+    const size_t NT = (size_t)v.N * v.T, LT = (size_t)v.L * v.T;
+    const size_t n1 = NT > LT ? NT : LT;
+    if (UPDATE && v.sliceDual) {
+        // level 2 of the consensus sum, here instead of behind a ticket in k_reduce: slice order, so the bits are
+        // the ones the two-level kernel produces
+        const int RB = v.reduceRB, N = v.N, T = v.T, R = 8;
+        const int r = tid >> 5, tt = tid & 31;            // 8 slice lanes x 32 entries, as in k_reduce
+        // N*T <= 256 here (slice_dual() in dopf_api.hip): up to 8 chunks of 32 entries, every load of every chunk
+        // issued before the first use, ONE barrier
+        double sc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const size_t i = (size_t)c * 32 + tt;
+            sc[c] = 0.0;
+            if (i < NT) {
+                const int n = (int)(i % N), t = (int)(i / N);
+                double x[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int q = r + R * k;
+                    x[k] = q < RB ? v.part2[((size_t)n * RB + q) * T + t] : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sc[c] += x[k];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) red[c][tid] = sc[c];
+        __syncthreads();
+        if (r == 0) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const size_t i = (size_t)c * 32 + tt;
+                if (i < NT) {
+                    double tot = 0.0;
+                    for (int q = 0; q < R; ++q) tot += red[c][q * 32 + tt];
+                    v.cons[i] = tot;
+                }
+            }
+        }
+        __syncthreads();
+        // cost slices: loaded side by side (one lane adding them from memory is a chain of RB dependent loads —
+        // 8 us for 64 slices)
+        if (tid < 64) {                                   // wave 0: a butterfly is a fixed order too
+            double c = tid < RB ? v.part2_cost[tid] : 0.0;
+            for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+            if (tid == 0) v.cons[NT + 2 * LT] = c;
+        }
+        __syncthreads();
+    }
+    double rl = 0.0, rm = 0.0, rr = 0.0;
+    for (size_t i = tid; i < n1; i += 256) dual_body<UPDATE>(v, i, rl, rm, rr);
+    if (UPDATE) {
+        red[0][tid] = rl; red[1][tid] = rm; red[2][tid] = rr;
+        if (tid == 0) v.st->total_cost = v.cons[NT + 2 * LT];
+    }
+    __syncthreads();                       // the block's own global writes (new duals) are visible after this
+    for (size_t i = tid; i < NT; i += 256) price_body(v, i);
+    if (UPDATE) {
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) {
+                red[0][tid] = fmax(red[0][tid], red[0][tid + s]);
+                red[1][tid] = fmax(red[1][tid], red[1][tid + s]);
+                red[2][tid] = fmax(red[2][tid], red[2][tid + s]);
+            }
+            __syncthreads();
+        }
+        if (tid == 0) status_update(v, red[0][0], red[1][0], red[2][0]);
+    }
+}
+
+void launch_dual(const DevView &v, hipStream_t s)
+{
+    const size_t NT = (size_t)v.N * v.T, LT = (size_t)v.L * v.T;
+    const size_t n1 = NT > LT ? NT : LT;
+    if (n1 <= kSmallConsensus) {
+        hipLaunchKernelGGL(k_dual_price_small<true>, dim3(1), dim3(256), 0, s, v);
+        return;
+    }
+    hipLaunchKernelGGL(k_dual<true>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, v);
+    hipLaunchKernelGGL(k_price<true>, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// set_state support: consensus sums straight from the primal arrays (slow path, not on the hot loop)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_derive_cons(DevView v)
+{
+    const int N = v.N, T = v.T;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)N * T) return;
+    const int n = (int)(i % N), t = (int)(i / N);
+    double sum = 0.0;
+    for (int g = v.node_gen_beg[n]; g < v.node_gen_beg[n + 1]; ++g) sum += v.P[(size_t)g * T + t];
+    for (int s = v.node_sto_beg[n]; s < v.node_sto_beg[n + 1]; ++s) sum += v.D[(size_t)s * T + t] - v.C[(size_t)s * T + t];
+    v.cons[i] = sum;
+}
+
+__global__ __launch_bounds__(256) void k_derive_level(DevView v)
+{
+    const int T = v.T;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= v.S) return;
+    double e = 0.0;
+    for (int t = 0; t < T; ++t) {
+        e += v.C[(size_t)s * T + t] - v.D[(size_t)s * T + t];
+        v.E[(size_t)s * T + t] = e;
+    }
+}
+
+void launch_derive(const DevView &v, hipStream_t s, bool from_primal)
+{
+    const size_t NT = (size_t)v.N * v.T, LT = (size_t)v.L * v.T;
+    const size_t n1 = NT > LT ? NT : LT;
+    if (from_primal) {        // serial over a node's agents: fine for tests / resume, not a hot path
+        hipLaunchKernelGGL(k_derive_cons, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, v);
+        if (v.S > 0) hipLaunchKernelGGL(k_derive_level, dim3((unsigned)((v.S + 255) / 256)), dim3(256), 0, s, v);
+    }
+    if (n1 <= kSmallConsensus) {
+        hipLaunchKernelGGL(k_dual_price_small<false>, dim3(1), dim3(256), 0, s, v);
+        return;
+    }
+    hipLaunchKernelGGL(k_dual<false>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, v);
+    hipLaunchKernelGGL(k_price<false>, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, v);
+}
+
+}  // namespace dopf

@@ -184,3 +184,23 @@ def test_sharding_is_a_partition_of_a_sum(oracle_api):
         P = np.concatenate([g["P"] for g in got])
         D = np.concatenate([g["D"] for g in got])
         assert np.abs(P - want["P"]).max() < 1e-9 and np.abs(D - want["D"]).max() < 1e-9
+
+
+def test_oracle_exact_mode_ignores_noise_level_ptdf_entries(oracle_api):
+    """A 4-node network whose PTDF holds entries of 1e-16 (rounding noise of the inverse): their kinks sit at 1e19,
+    where the exact mode's tables used to lose all precision (all generators of a node flipped to pmax at some
+    timesteps). Found by scripts/fuzz_parity.py — HIP and the literal mode agreed, the exact mode did not."""
+    from decentralopf_jl_amd import synth
+    from helpers import make_engine, state_of, max_diff
+    pp = synth.synthetic_case(n_gen=31, n_sto=0, T=30, N=4, L=3, seed=153374, fmax_factor=0.5, fmax_min=1.0)
+    assert 0 < np.abs(pp.ptdf)[np.abs(pp.ptdf) > 0].min() < 1e-12          # the case really has such entries
+    params = dict(gamma=0.03225806451612903, w_flow=0.1, eps=0.0)
+    lit = make_engine(oracle_api, pp, mode=0, **params)
+    exa = make_engine(oracle_api, pp, mode=1, **params)
+    for _ in range(4):
+        lit.iterate(1)
+        exa.iterate(1)
+        sl, se = state_of(lit), state_of(exa)
+        assert max_diff(sl, se, keys=[k for k in sl if k != "cost"])[0] < 1e-6
+        exa.set_state(P=sl["P"], D=sl["D"], C_=sl["C"], avg_U=sl["avg_U"], avg_K=sl["avg_K"], lam=sl["lam"], mu=sl["mu"],
+                      rho=sl["rho"], iteration=lit.get_residuals()[3])
