@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="fork the storage kernel onto a side stream")
     ap.add_argument("--flags", type=int, default=0, help="DOPF_F_* bits (include/dopf.h), e.g. 16 = separate generator/storage launches")
     ap.add_argument("--no-also", action="store_true", help="skip the short side runs of the other single-GPU workloads")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl (= RCCL) is the product path, gloo only to "
+                                                      "rehearse the multi-rank logic on a box with fewer GPUs than ranks")
     ap.add_argument("--force-sharded", action="store_true", help="debug: drive the sharded (all-reduce) path even on one rank")
     args = ap.parse_args()
 
@@ -112,6 +114,7 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    local_rank %= max(1, torch.cuda.device_count())       # (ranks > GPUs only happens in a rehearsal on a small box)
     torch.cuda.set_device(local_rank)
     dist = None
     sharded = world > 1 or args.force_sharded
@@ -119,7 +122,10 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     idx, desc = WORKLOADS[args.workload]
     # weak scaling: every rank owns one full grid of the workload (own seed), demand adds up
