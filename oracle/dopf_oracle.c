@@ -95,9 +95,9 @@ static void lu_solve(int n, const double *a, const int *piv, double *x)
 /* stands in for `optimize!(sub)` = JuMP -> Gurobi barrier, subproblems.jl:86,186              */
 /* ------------------------------------------------------------------------------------------ */
 
-int oracle_qp_solve(int32_t n, int32_t m, const double *Q, const double *c0, const double *A,
-                    const double *b0, const double *lb, const double *ub, double *xout,
-                    double *yout, int32_t *iters_out)
+static int qp_solve_from(int32_t n, int32_t m, const double *Q, const double *c0, const double *A,
+                         const double *b0, const double *lb, const double *ub, double *xout,
+                         double *yout, int32_t *iters_out, int scaled_start)
 {
     int rc = -1;
     double *c = dalloc(n), *b = dalloc(m), *u = dalloc(n);
@@ -141,11 +141,15 @@ int oracle_qp_solve(int32_t n, int32_t m, const double *Q, const double *c0, con
             x[i] = 0.5 * w; t[i] = w - x[i]; s[i] = 1.0;
             u[i] = w;
         } else {
-            x[i] = 10.0; t[i] = 1.0; s[i] = 0.0;
+            /* second try: start an unbounded variable at the scale its own curvature suggests (the slack of a
+             * line that is overloaded by thousands sits far from 10) */
+            x[i] = scaled_start ? dmax(10.0, cnorm / dmax(Q[i * n + i], 1e-3)) : 10.0; t[i] = 1.0; s[i] = 0.0;
         }
         z[i] = 1.0;
     }
     const double tol_d = 1e-12 * (1.0 + cnorm), tol_p = 1e-12 * (1.0 + bnorm), tol_mu = 1e-15;
+    /* "close": the merit the fp64 floor allows scales with the size of the gradient / right-hand side */
+    const double close = 1e-6 * (1.0 + cnorm + bnorm);
     double best = INFINITY;
     int stall = 0;
 
@@ -171,21 +175,21 @@ int oracle_qp_solve(int32_t n, int32_t m, const double *Q, const double *c0, con
         if (merit < best) { memcpy(xbest, x, sizeof(double) * n); memcpy(ybest, y, sizeof(double) * (m ? m : 1)); }
         if (rdn <= tol_d && rpn <= tol_p && mu <= tol_mu) { best = merit; break; }
         if (merit < best * 0.999) { best = merit; stall = 0; }
-        else if (best < 1e-6 && ++stall > 6) break;   /* fp64 floor reached */
+        else if (best < close && ++stall > 6) break;   /* fp64 floor reached */
 
         for (int i = 0; i < n; ++i) {
             for (int j = 0; j < n; ++j) M[i * n + j] = Q[i * n + j];
             M[i * n + i] += z[i] / x[i] + (bounded[i] ? s[i] / t[i] : 0.0);
         }
         if (m == 0) {
-            if (chol_factor(n, M) != 0) { if (best < 1e-6) break; goto done; }
+            if (chol_factor(n, M) != 0) { if (best < close) break; goto done; }
         } else {
             for (int i = 0; i < n; ++i) {
                 for (int j = 0; j < n; ++j) KK[i * nk + j] = M[i * n + j];
                 for (int r = 0; r < m; ++r) { KK[i * nk + n + r] = -A[r * n + i]; KK[(n + r) * nk + i] = A[r * n + i]; }
             }
             for (int r = 0; r < m; ++r) for (int q = 0; q < m; ++q) KK[(n + r) * nk + n + q] = 0.0;
-            if (lu_factor(nk, KK, kpiv) != 0) { if (best < 1e-6) break; goto done; }
+            if (lu_factor(nk, KK, kpiv) != 0) { if (best < close) break; goto done; }
         }
 
         double sigma = 0.0;
@@ -247,7 +251,7 @@ int oracle_qp_solve(int32_t n, int32_t m, const double *Q, const double *c0, con
             }
         }
     }
-    if (!(best < 1e-6)) goto done;          /* never got close: report failure */
+    if (!(best < close)) goto done;         /* never got close: report failure */
     for (int i = 0; i < n; ++i) xout[i] = lb[i] + xbest[i];
     if (yout) for (int r = 0; r < m; ++r) yout[r] = ybest[r];
     rc = 0;
@@ -256,6 +260,17 @@ done:
     free(c); free(b); free(u); free(x); free(z); free(t); free(s); free(y); free(rd); free(rp);
     free(M); free(rhs); free(dx); free(dz); free(ds); free(dy); free(dxa); free(dza); free(dsa);
     free(KK); free(sol); free(kpiv); free(bounded); free(xbest); free(ybest);
+    return rc;
+}
+
+/* Mehrotra from the plain starting point; if that does not get close (seen on random network cases whose line
+ * slacks sit thousands away from the start), once more from a starting point scaled to the problem. */
+int oracle_qp_solve(int32_t n, int32_t m, const double *Q, const double *c0, const double *A,
+                    const double *b0, const double *lb, const double *ub, double *xout,
+                    double *yout, int32_t *iters_out)
+{
+    int rc = qp_solve_from(n, m, Q, c0, A, b0, lb, ub, xout, yout, iters_out, 0);
+    if (rc != 0) rc = qp_solve_from(n, m, Q, c0, A, b0, lb, ub, xout, yout, iters_out, 1);
     return rc;
 }
 
