@@ -147,6 +147,16 @@ static int qp_solve_from(int32_t n, int32_t m, const double *Q, const double *c0
         }
         z[i] = 1.0;
     }
+    if (scaled_start) {
+        /* ... and the multipliers so that the dual residual Qx + c - z + s starts at (almost) zero: with z = 1 against a
+         * gradient of hundreds the first step blows the complementarity products up by six orders of magnitude */
+        for (int i = 0; i < n; ++i) {
+            double g = c[i];
+            for (int j = 0; j < n; ++j) g += Q[i * n + j] * x[j];
+            if (bounded[i]) { if (g >= 0) { z[i] = g + 1.0; s[i] = 1.0; } else { z[i] = 1.0; s[i] = 1.0 - g; } }
+            else z[i] = dmax(g, 1.0);
+        }
+    }
     const double tol_d = 1e-12 * (1.0 + cnorm), tol_p = 1e-12 * (1.0 + bnorm), tol_mu = 1e-15;
     /* "close": the merit the fp64 floor allows scales with the size of the gradient / right-hand side */
     const double close = 1e-6 * (1.0 + cnorm + bnorm);
