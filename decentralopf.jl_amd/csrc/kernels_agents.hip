@@ -511,6 +511,25 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
         accQ[c] = 0.0;
         th0[c] = (!LINES && t < T) ? v.price[it.node + N * t] + gam * v.s[t] : 0.0;
     }
+    // with lines: a (node, timestep) whose table is empty — no kink of Psi inside the node's window, the usual case —
+    // is the copper-plate closed form with (Psi(0), slope) in place of (theta, gamma): cached here, no table reads
+    double lp0[NCH], lkap[NCH], lia[NCH], lidet[NCH], ls2[NCH];
+    bool lin[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int t = tbase + c;
+        lin[c] = false; lp0[c] = 0.0; lkap[c] = 0.0; lia[c] = 0.0; lidet[c] = 0.0; ls2[c] = 0.0;
+        if (LINES && t < T) {
+            const size_t at = (size_t)it.node + (size_t)N * t;
+            if (v.tb_m[at] == 0) {
+                lin[c] = true;
+                lp0[c] = v.tb_psi0[at];
+                lkap[c] = v.tb_slope[at * (v.M2 + 1)];
+                const double a = w + lkap[c];
+                lia[c] = 1.0 / a; lidet[c] = 1.0 / (a * a - lkap[c] * lkap[c]); ls2[c] = 2.0 / (a + lkap[c]);
+            }
+        }
+    }
     unsigned long long fails = 0;
 #ifdef DOPF_STATS
     unsigned long long st_scans = 0, st_loops = 0, st_events = 0;
@@ -548,6 +567,11 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
                 box2(a0, gam, ia0, idet0, s20, w * D0[c] - ag.mc - theta - nu, w * C0[c] - ag.mc + theta + nu,
                      ag.pm, dd, cc, s1);
                 pc = theta + gam * (dd - cc);
+            } else if (lin[c]) {
+                const double q0 = D0[c] - C0[c], theta = lp0[c] - lkap[c] * q0;
+                box2(w + lkap[c], lkap[c], lia[c], lidet[c], ls2[c], w * D0[c] - ag.mc - theta - nu, w * C0[c] - ag.mc + theta + nu,
+                     ag.pm, dd, cc, s1);
+                pc = theta + lkap[c] * (dd - cc);
             } else {
                 const TabRef tb = tab_ref(v, it.node, tbase + c);
                 eval_lines(tb, hint[c], w, iw, ag.mc, ag.pm, D0[c], C0[c], nu, dd, cc, s1, pc);
@@ -917,6 +941,25 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
         accQ[c] = 0.0;
         th0[c] = (!LINES && t < T) ? v.price[it.node + N * t] + gam * v.s[t] : 0.0;
     }
+    // with lines: a (node, timestep) whose table is empty — no kink of Psi inside the node's window, the usual case —
+    // is the copper-plate closed form with (Psi(0), slope) in place of (theta, gamma): cached here, no table reads
+    double lp0[NCH], lkap[NCH], lia[NCH], lidet[NCH], ls2[NCH];
+    bool lin[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int t = tbase + c;
+        lin[c] = false; lp0[c] = 0.0; lkap[c] = 0.0; lia[c] = 0.0; lidet[c] = 0.0; ls2[c] = 0.0;
+        if (LINES && t < T) {
+            const size_t at = (size_t)it.node + (size_t)N * t;
+            if (v.tb_m[at] == 0) {
+                lin[c] = true;
+                lp0[c] = v.tb_psi0[at];
+                lkap[c] = v.tb_slope[at * (v.M2 + 1)];
+                const double a = w + lkap[c];
+                lia[c] = 1.0 / a; lidet[c] = 1.0 / (a * a - lkap[c] * lkap[c]); ls2[c] = 2.0 / (a + lkap[c]);
+            }
+        }
+    }
     const int nRep = (it.a1 - it.a0 + NG - 1) / NG;
     for (int rep = 0; rep < nRep; ++rep) {
         const int s = it.a0 + rep * NG + grp;
@@ -1000,6 +1043,10 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
                     if (!LINES) {
                         const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
                         box2(a0, gam, ia0, idet0, s20, w * D0[c] - mc - theta - nuv[c], w * C0[c] - mc + theta + nuv[c], pm, dd, cc, s1);
+                    } else if (lin[c]) {
+                        const double q0 = D0[c] - C0[c], theta = lp0[c] - lkap[c] * q0;
+                        box2(w + lkap[c], lkap[c], lia[c], lidet[c], ls2[c], w * D0[c] - mc - theta - nuv[c], w * C0[c] - mc + theta + nuv[c],
+                             pm, dd, cc, s1);
                     } else {
                         const TabRef tb = tab_ref(v, it.node, t);
                         double pcx;
@@ -1128,7 +1175,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
                     } else if (kind[c] != 0 && st[c] && base[t] == tgt[c]) {
                         // idle on a bound: with D = C = 0 the step's net injection is unchanged at q = 0: dlt = -q0
                         const double q0 = D0[c] - C0[c];
-                        const double theta = tab_psi_at(tab_ref(v, it.node, t), -q0);
+                        const double theta = lin[c] ? lp0[c] - lkap[c] * q0 : tab_psi_at(tab_ref(v, it.node, t), -q0);
                         const double rD0 = w * D0[c] - mc - theta, rC0 = w * C0[c] - mc + theta;
                         if (rD0 <= -rC0 && nuv[c] >= rD0 - 1e-9 && nuv[c] <= -rC0 + 1e-9) { mlo[c] = rD0; mhi[c] = -rC0; }
                     }
