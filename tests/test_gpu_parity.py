@@ -62,6 +62,8 @@ SYNTH = [
     ("copper-T600-gen-only", dict(n_gen=30, n_sto=0, T=600, seed=8), dict(gamma=0.02), 1, 5, 1e-9),
     ("copper-gamma1-diverging", dict(n_gen=60, n_sto=12, T=24, seed=12), dict(gamma=1.0), 1, 25, 1e-7),
     ("copper-multinode", dict(n_gen=40, n_sto=10, T=12, N=5, seed=13), dict(gamma=0.02), 1, 20, 1e-9),
+    ("copper-30-nodes-two-level-reduce", dict(n_gen=200, n_sto=40, T=24, N=30, seed=33), dict(gamma=0.004), 1, 15, 1e-9),
+    ("copper-200-nodes-dual-per-timestep", dict(n_gen=600, n_sto=60, T=24, N=200, seed=34), dict(gamma=0.0015), 1, 8, 1e-9),
     ("net-4x5", dict(n_gen=12, n_sto=4, T=5, N=4, L=5, seed=5, fmax_factor=0.7, fmax_min=5), dict(gamma=0.1), 1, 40, 1e-8),
     ("net-4x5-literal", dict(n_gen=12, n_sto=4, T=5, N=4, L=5, seed=5, fmax_factor=0.7, fmax_min=5), dict(gamma=0.1), 0, 15, 1e-6),
     ("net-6x9", dict(n_gen=60, n_sto=15, T=24, N=6, L=9, seed=7, fmax_factor=0.6, fmax_min=5), dict(gamma=0.05), 1, 30, 1e-8),
