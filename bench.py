@@ -162,9 +162,8 @@ def main():
         sh = ShardedADMM(pp, 0, 1, gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank, n_agents_global_override=A_global)
         st, tens = sh.stream, sh._tensor
 
-        def _all_reduce():
-            with torch.cuda.stream(st):
-                dist.all_reduce(tens, op=dist.ReduceOp.SUM)
+        def _all_reduce():                # (ShardedADMM.step makes the engine's stream current around its loop)
+            dist.all_reduce(tens, op=dist.ReduceOp.SUM)
         sh._all_reduce = _all_reduce
         eng = sh.engine
         step = lambda n: sh.step(n)

@@ -61,11 +61,10 @@ class ShardedADMM:
             self.engine.bind_consensus(self._tensor.data_ptr())
             if all_reduce is None:
                 if world > 1:
-                    t, st = self._tensor, self.stream
+                    t = self._tensor
 
-                    def all_reduce():
-                        with torch.cuda.stream(st):
-                            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                    def all_reduce():                 # runs on the engine's stream: step() makes it current
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM)
                 else:
                     all_reduce = lambda: None
         else:
@@ -80,6 +79,14 @@ class ShardedADMM:
     def step(self, n: int = 1) -> None:
         """n iterations, enqueued without host synchronisation (converged state is frozen on device)."""
         e = self.engine
+        if self._tensor is not None:          # product path: the collective must queue on the kernels' stream
+            import torch
+            with torch.cuda.stream(self.stream):      # entered once per call, not once per iteration
+                for _ in range(n):
+                    e.local_update()
+                    self._all_reduce()
+                    e.apply_consensus()
+            return
         for _ in range(n):
             e.local_update()
             self._all_reduce()
