@@ -290,7 +290,7 @@ def main():
             out["agents_fused"] = fused
             if not fused:
                 s_ms = max(timing["sto_ms"] - timing["empty_ms"], 1e-6)
-                out["storage_kernel"] = {"kernel": "k_sto_warm + k_sto_update", "bound": "fp64 VALU (segmented Newton + certificate; scan fallback), not HBM",
+                out["storage_kernel"] = {"kernel": "k_sto (warm start, then the cold scan for what it left over)" if pp.L == 0 else "k_sto_warm + k_sto_update", "bound": "fp64 VALU (segmented Newton + certificate; scan fallback), not HBM",
                                          "algorithmic_bytes_per_launch": sto_b, "kernel_ms": s_ms,
                                          "achieved_GBps": sto_b / s_ms * 1e-6}
             whole = (gen_b + sto_b + shared_b) / (dt / args.steps) / 1e9
