@@ -293,6 +293,21 @@ def main():
                 out["storage_kernel"] = {"kernel": "k_sto (warm start, then the cold scan for what it left over)" if pp.L == 0 else "k_sto_warm + k_sto_update", "bound": "fp64 VALU (segmented Newton + certificate; scan fallback), not HBM",
                                          "algorithmic_bytes_per_launch": sto_b, "kernel_ms": s_ms,
                                          "achieved_GBps": sto_b / s_ms * 1e-6}
+            if fused and world == 1 and not args.force_sharded:
+                # the two halves of k_agents on their own (separate launches, DOPF_F_NO_FUSE), steady state: the generator
+                # sweep is the HBM-bound part, the storage solve the latency-bound one
+                ex = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank,
+                                                                               flags=args.flags | _capi.F_NO_FUSE), **pp.engine_kwargs())
+                ex.iterate(args.warmup + args.steps - steady["iters"])
+                tx = ex.iterate_timed(steady["iters"])
+                ex.close()
+                g_ms, s_ms2 = max(tx["gen_ms"] - tx["empty_ms"], 1e-6), max(tx["sto_ms"] - tx["empty_ms"], 1e-6)
+                out["roofline"]["parts_as_separate_launches"] = {
+                    "k_gen_update_pair": {"kernel_ms": g_ms, "algorithmic_bytes_per_launch": gen_b + shared_b,
+                                          "achieved": (gen_b + shared_b) / g_ms * 1e-6, "frac": (gen_b + shared_b) / g_ms * 1e-6 / peak},
+                    "k_sto (warm start + cold scan)": {"kernel_ms": s_ms2, "algorithmic_bytes_per_launch": sto_b,
+                                                       "achieved": sto_b / s_ms2 * 1e-6, "frac": sto_b / s_ms2 * 1e-6 / peak},
+                    "window": f"iterations {args.warmup + args.steps - steady['iters']}..{args.warmup + args.steps - 1}, as the steady state above"}
             whole = (gen_b + sto_b + shared_b) / (dt / args.steps) / 1e9
             out["whole_iteration_GBps"] = whole
             out["whole_iteration_frac_of_peak"] = whole / peak
