@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 from decentralopf_jl_amd import _capi
 
@@ -49,3 +51,33 @@ def test_no_cpu_fallback_in_product_package():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "libdopf_oracle" not in text and "dopf_oracle" not in text, f
                 assert "oracle_create" not in text and "ORACLE_LIB" not in text, f
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "decentralopf.jl_amd", "csrc")
+    exe = str(tmp_path / "three_node")
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "three_node.c"),
+                    "-o", exe, "-L" + lib_dir, "-ldopf_hip", "-Wl,-rpath," + lib_dir], check=True)
+    return exe
+
+
+def test_c_example_builds_against_the_abi_and_fails_loudly_without_a_gpu(tmp_path):
+    """examples/three_node.c: plain C against include/dopf.h + libdopf_hip.so. Here (no GPU) it must refuse to run."""
+    import subprocess
+    import torch
+    exe = _build_c_example(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked test")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_c_example_reproduces_the_reference_run(tmp_path):
+    """The shipped three-node case from C: 476 iterations, cost 14034.51 (thesis Table 16), prices of Table 17."""
+    import subprocess
+    r = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "converged after 476 iterations, total cost 14034.51" in r.stdout
