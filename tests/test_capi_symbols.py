@@ -81,3 +81,5 @@ def test_c_example_reproduces_the_reference_run(tmp_path):
     r = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "converged after 476 iterations, total cost 14034.51" in r.stdout
+    assert "t=1 nodal prices -36.597 -15.216 -30.000" in r.stdout           # thesis Table 17 (tests/golden/thesis_tables.json)
+    assert "t=2 nodal prices -81.976 -4.013 -30.000" in r.stdout
