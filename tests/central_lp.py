@@ -67,3 +67,20 @@ def solve_central(pp):
     return dict(objective=res.fun, P=x[:nP].reshape(G, T), D=x[nP:nP + nS].reshape(S, T),
                 C=x[nP + nS:nP + 2 * nS].reshape(S, T), E=x[nP + 2 * nS:].reshape(S, T),
                 lam=res.eqlin.marginals[:T])
+
+
+def aggregate_copper_plate(pp):
+    """Copper plate (N = 1, L = 0): units with identical parameters are interchangeable in the LP, so the optimum of
+    the case with one unit per class (capacities added up) equals the optimum of the full case — generators by
+    marginal cost, storages by (marginal cost, pmax, emax). Turns the 24-million-variable LP of the 1M-agent
+    configuration into one with a few thousand variables."""
+    if pp.N != 1 or pp.L != 0:
+        raise ValueError("aggregation is exact only without a network")
+    gm, ginv = np.unique(pp.gen_mc, return_inverse=True)
+    gp = np.bincount(ginv, weights=pp.gen_pmax, minlength=gm.size)
+    keys = np.stack([pp.sto_mc, pp.sto_pmax, pp.sto_emax], axis=1) if pp.S else np.zeros((0, 3))
+    sk, sinv = np.unique(keys, axis=0, return_inverse=True) if pp.S else (np.zeros((0, 3)), np.zeros(0, dtype=int))
+    cnt = np.bincount(sinv.ravel(), minlength=sk.shape[0]) if pp.S else np.zeros(0)
+    return type(pp)(N=1, L=0, T=pp.T, demand=pp.demand, ptdf=pp.ptdf, f_max=pp.f_max, gen_mc=gm, gen_pmax=gp,
+                    gen_node=np.zeros(gm.size, dtype=np.int32), sto_mc=sk[:, 0], sto_pmax=sk[:, 1] * cnt, sto_emax=sk[:, 2] * cnt,
+                    sto_node=np.zeros(sk.shape[0], dtype=np.int32), meta=dict(aggregated_from=(pp.G, pp.S)))

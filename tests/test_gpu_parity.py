@@ -311,6 +311,20 @@ def test_hip_config2_time_to_residual_and_optimum(hip_api):
     assert e.solver_failures() == 0
 
 
+def test_hip_config4_reaches_central_optimum(hip_api):
+    """BASELINE config 4 (1M agents x 24): the 1e-3 residual is reached in ~650 iterations and the cost sits within
+    1e-3 (in fact 4e-6) of the central LP optimum (aggregated LP, tests/golden/synthetic_optima.json)."""
+    from conftest import load_golden
+    pp = synth.baseline_config(4)
+    opt = load_golden("synthetic_optima")["config4"]
+    assert (opt["G"], opt["S"], opt["T"]) == (pp.G, pp.S, pp.T)
+    e = make_engine(hip_api, pp, gamma=1.0 / (pp.G + pp.S), max_iters=5000)
+    done, conv = e.iterate(5000)
+    assert conv and done < 1500
+    assert abs(e.get_consensus()[4] - opt["objective"]) / opt["objective"] < 1e-3
+    assert e.solver_failures() == 0
+
+
 def test_hip_config1_reaches_central_optimum(hip_api):
     """BASELINE config 1 (1000 gens + 100 storages x 24): converges (gamma = 1/A) to the LP optimum."""
     pp = synth.baseline_config(1)

@@ -204,3 +204,16 @@ def test_oracle_exact_mode_ignores_noise_level_ptdf_entries(oracle_api):
         assert max_diff(sl, se, keys=[k for k in sl if k != "cost"])[0] < 1e-6
         exa.set_state(P=sl["P"], D=sl["D"], C_=sl["C"], avg_U=sl["avg_U"], avg_K=sl["avg_K"], lam=sl["lam"], mu=sl["mu"],
                       rho=sl["rho"], iteration=lit.get_residuals()[3])
+
+
+def test_aggregated_central_lp_equals_the_full_one():
+    """tests/central_lp.aggregate_copper_plate (how the 1M-agent optimum is obtained): same optimum as the full LP."""
+    from decentralopf_jl_amd import synth
+    from central_lp import aggregate_copper_plate
+    pp = synth.synthetic_case(300, 60, 12, seed=77)
+    ag = aggregate_copper_plate(pp)
+    assert ag.G <= 60 and ag.S < pp.S
+    full, agg = solve_central(pp)["objective"], solve_central(ag)["objective"]
+    assert abs(full - agg) <= 1e-9 * full
+    with pytest.raises(ValueError):
+        aggregate_copper_plate(synth.synthetic_case(10, 2, 3, N=3, L=2, seed=1))
