@@ -14,7 +14,7 @@ import dopf_pkg  # noqa: E402
 
 dopf_pkg.load()
 from decentralopf_jl_amd import synth  # noqa: E402
-from central_lp import aggregate_copper_plate, solve_central  # noqa: E402
+from central_lp import aggregate_copper_plate, solve_central, solve_central_nodal  # noqa: E402
 
 out = {"source": "scipy.optimize.linprog(method='highs') on synth.baseline_config(i); objective = sum mc*P + sum mc*(D+C)"}
 for idx in (1, 2):
@@ -34,4 +34,10 @@ for idx in (1, 2, 4):
         out[f"config{idx}"] = {"G": pp.G, "S": pp.S, "T": pp.T, "objective": r["objective"], "seed": synth.SEED,
                                "how": "aggregated LP (one unit per parameter class)"}
     print(idx, "aggregated", r["objective"])
+# one GPU's share of the 118-node network configuration (12 500 agents x 168): nodal-injection formulation, ~2 min
+pp = synth.baseline_config(3, scale=0.125)
+r = solve_central_nodal(pp)
+out["config3-share"] = {"G": pp.G, "S": pp.S, "T": pp.T, "N": pp.N, "L": pp.L, "objective": r["objective"], "seed": synth.SEED,
+                        "how": "synth.baseline_config(3, scale=0.125); LP with explicit nodal injections (central_lp.solve_central_nodal)"}
+print("config3-share", r["objective"])
 json.dump(out, open(os.path.join(HERE, "synthetic_optima.json"), "w"), indent=1)

@@ -325,6 +325,23 @@ def test_hip_config4_reaches_central_optimum(hip_api):
     assert e.solver_failures() == 0
 
 
+def test_hip_network_share_reaches_central_optimum(hip_api):
+    """One GPU's share of BASELINE config 3 (118 nodes, 186 lines, 12 500 agents x 168), flow weight 0.3/A: converges
+    in ~670 iterations to within 1e-3 (in fact 7e-7) of the central LP optimum (tests/golden/synthetic_optima.json)."""
+    from conftest import load_golden
+    pp = synth.baseline_config(3, scale=0.125)
+    opt = load_golden("synthetic_optima")["config3-share"]
+    assert (opt["G"], opt["S"], opt["T"], opt["N"], opt["L"]) == (pp.G, pp.S, pp.T, pp.N, pp.L)
+    A = pp.G + pp.S
+    e = make_engine(hip_api, pp, gamma=1.0 / A, w_flow=0.3 / A, max_iters=5000)
+    done, conv = e.iterate(5000)
+    assert conv and done < 1500
+    inj, aU, aK, flow, cost = e.get_consensus()
+    assert abs(cost - opt["objective"]) / opt["objective"] < 1e-3
+    assert (np.abs(flow) - pp.f_max[:, None]).max() <= 1e-6 * pp.f_max.max()
+    assert e.solver_failures() == 0
+
+
 def test_hip_config1_reaches_central_optimum(hip_api):
     """BASELINE config 1 (1000 gens + 100 storages x 24): converges (gamma = 1/A) to the LP optimum."""
     pp = synth.baseline_config(1)

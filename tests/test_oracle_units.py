@@ -217,3 +217,13 @@ def test_aggregated_central_lp_equals_the_full_one():
     assert abs(full - agg) <= 1e-9 * full
     with pytest.raises(ValueError):
         aggregate_copper_plate(synth.synthetic_case(10, 2, 3, N=3, L=2, seed=1))
+
+
+def test_nodal_central_lp_equals_the_unit_formulation():
+    """tests/central_lp.solve_central_nodal (explicit nodal injections: how the 118-node share's optimum is obtained)."""
+    from decentralopf_jl_amd import synth
+    from central_lp import solve_central_nodal
+    for case in (dict(n_gen=40, n_sto=8, T=6, N=5, L=6, seed=3, fmax_factor=0.8, fmax_min=5), dict(n_gen=30, n_sto=5, T=8, seed=2)):
+        pp = synth.synthetic_case(**case)
+        a, b = solve_central(pp)["objective"], solve_central_nodal(pp)["objective"]
+        assert abs(a - b) <= 1e-9 * abs(a)
