@@ -813,19 +813,27 @@ __global__ __launch_bounds__(256) void k_sto_update(DevView v)
 }
 
 // ------------------------------------------------------------------------------------------------
-// storages, warm start: re-solve on the previous iteration's structure, accept only with a certificate
+// storages, active-set solve: all constant-price segments at once, contact set repaired between rounds
 // ------------------------------------------------------------------------------------------------
 //
-// Near convergence the SET of timesteps at which a storage is full or empty does not change from one
-// ADMM iteration to the next. This kernel takes that set from the previous level trajectory, gives every
-// segment between two contacts one price and solves sum_{t in seg} x_t(nu) = level change of the segment
-// for all segments at once (segmented Newton: a segmented scan supplies the sums, LDS hands the new
-// price back to the segment's timesteps), then CHECKS the KKT conditions of the storage QP:
-//   levels within [0, emax]; at a contact at 0 the price may only fall going forward, at emax only rise;
-//   the open last segment has price 0 (nu_{T+1} = 0).
-// The QP is strictly convex in (D, C), so a point that passes is THE minimiser — whatever produced the
-// guess. Storages that fail (structure changed, Newton stalled, no previous prices) are left untouched
-// and flagged for the scan kernel. Cost is independent of the number of contacts.
+// The storage QP in dual form is max_nu sum_t phi_t(nu_t) - emax sum_t max(0, nu_{t+1} - nu_t): the price of
+// stored energy nu is piecewise constant in time and may only fall going forward where the level sits at 0
+// ("empty contact") and only rise where it sits at emax ("full contact"). For a GUESS of the contact set
+// every segment between two contacts has one price, fixed by sum_{t in seg} x_t(nu) = level change of the
+// segment; all segments are solved at once (segmented, bracketed Newton on the piecewise-linear sums: a
+// segmented DPP scan supplies sum x and sum dx/dnu per segment, LDS hands the new price back to the segment's
+// timesteps; a segment whose steps all sit on corners of their (D, C) box jumps just past the nearest kink).
+// Then the KKT conditions of the QP are CHECKED (levels within [0, emax]; price jumps at the contacts have
+// the right sign, with whole intervals of multipliers for segments that do not move with their price;
+// nu = 0 on the open last segment). The QP is strictly convex in (D, C): a point that passes is THE
+// minimiser, whatever produced the guess. A guess that fails is repaired the primal-dual-active-set way —
+// every step whose level left the band becomes a contact at the bound it crossed, every contact whose price
+// jump has the wrong sign is released — and the solve is repeated. Round 0 starts from the previous
+// iteration's contact set (read off the previous level trajectory: no extra state) and prices (8T bytes of
+// solver state per storage): near convergence it certifies at once (the "warm start"); from the zero state,
+// or after the contact structure moved, a handful of rounds do. Cost per round does not depend on the number
+// of contacts. Storages that are not certified within the round budget are left untouched and flagged for
+// the scan kernel (the safeguarded, exact fallback).
 
 // inclusive segmented scan of (a, b) over the lanes of each group; f = "a segment starts in this lane"
 template <int LPS>
@@ -906,6 +914,27 @@ __device__ __forceinline__ void scan_clamps_rev(double &lo, double &hi, int lane
     }
 }
 
+// suffix (right-to-left) inclusive min over the lanes of each group
+template <int LPS>
+__device__ __forceinline__ int scan_min_rev_i(int x, int lane)
+{
+    constexpr int RL = LPS < 16 ? LPS : 16;
+    const int r = lane & (RL - 1);
+#define DOPF_REVI_STEP(CTRL, D)                                                      \
+    {                                                                                \
+        const int g = __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false);      \
+        if (r + D < RL) x = g < x ? g : x;                                           \
+    }
+    DOPF_REVI_STEP(0x101, 1)                    // row_shl:1
+    if (LPS >= 4) DOPF_REVI_STEP(0x102, 2)
+    if (LPS >= 8) DOPF_REVI_STEP(0x104, 4)
+    if (LPS >= 16) DOPF_REVI_STEP(0x108, 8)
+#undef DOPF_REVI_STEP
+    if (LPS >= 32) { const int g = __shfl(x, (lane | 15) + 1); if ((lane & 16) == 0) x = g < x ? g : x; }
+    if (LPS >= 64) { const int g = __shfl(x, 32); if ((lane & 32) == 0) x = g < x ? g : x; }
+    return x;
+}
+
 // value of the next lane of the group (garbage for the group's last lane: caller masks it)
 template <int LPS>
 __device__ __forceinline__ double next_lane(double x)
@@ -914,23 +943,32 @@ __device__ __forceinline__ double next_lane(double x)
     return dppd<0x130, 0xF>(x, x);                     // wave_shl:1
 }
 
+template <int LPS>
+__device__ __forceinline__ int next_lane_i(int x)
+{
+    if (LPS <= 16) return __builtin_amdgcn_update_dpp(x, x, 0x101, 0xF, 0xF, false);
+    return __builtin_amdgcn_update_dpp(x, x, 0x130, 0xF, 0xF, false);
+}
+
 // returns the number of storages of the item left to the scan (block-uniform)
 template <int LPS, int NCH, bool LINES>
 __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
 {
     constexpr int NG = 256 / LPS, TP = LPS * NCH;
+    constexpr int MAXR = 16;                 // contact-set rounds per storage
+    constexpr int MAXN = 40;                 // Newton iterations per round
+    constexpr int BIG = 0x3fffffff;
     __shared__ double red[NG * TP];          // also nuL during the solve
     __shared__ double baseL[NG * TP];
-    __shared__ int keyL[NG * TP];
     __shared__ double redc[256];
     const int tid = threadIdx.x, lane = tid & 63, li = tid & (LPS - 1), grp = tid / LPS;
+    const int gbase = lane & ~(LPS - 1);
     const Item it = v.sto_items[blk];
     const int T = v.T, N = v.N;
     const double w = v.w_prox, gam = v.gamma;
     const double a0 = w + gam, ia0 = 1.0 / a0, idet0 = 1.0 / (a0 * a0 - gam * gam), s20 = 2.0 / (a0 + gam);
     const int tbase = li * NCH;
     double *nuL = red + grp * TP, *base = baseL + grp * TP;
-    int *key = keyL + grp * TP;
 
     double th0[NCH], accQ[NCH];
     double accCost = 0.0;
@@ -960,12 +998,15 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
             }
         }
     }
+#ifdef DOPF_STATS
+    unsigned long long st_rounds = 0, st_newton = 0;
+#endif
     const int nRep = (it.a1 - it.a0 + NG - 1) / NG;
     for (int rep = 0; rep < nRep; ++rep) {
         const int s = it.a0 + rep * NG + grp;
         const bool live = s < it.a1;
         const double mc = live ? v.sto_mc[s] : 0.0, pm = live ? v.sto_pmax[s] : 0.0, em = live ? v.sto_emax[s] : 0.0;
-        bool good = live && v.nu_valid[s] != 0;
+        const bool havenu = live && v.nu_valid[s] != 0;
         double D0[NCH], C0[NCH], nuv[NCH];
         int hint[NCH];
         const double iw = 1.0 / w;
@@ -977,264 +1018,365 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
             const size_t e = (size_t)s * T + (ok ? t : 0);
             D0[c] = ok ? v.D[e] : 0.0;
             C0[c] = ok ? v.C[e] : 0.0;
-            nuv[c] = ok ? v.nu_prev[e] : 0.0;
+            nuv[c] = (ok && havenu) ? v.nu_prev[e] : 0.0;      // no stored prices (zero state, set_state): start from 0
             hint[c] = 0;
             run += C0[c] - D0[c];
         }
-        // previous level trajectory -> contacts -> segment ends
+        // (D, C)(nu) of step c, d(C - D)/dnu, Psi at the step's net injection
+        auto eval = [&](int c, double nu, double &dd, double &cc, double &s1, double &pc) {
+            if (!LINES) {
+                const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
+                box2(a0, gam, ia0, idet0, s20, w * D0[c] - mc - theta - nu, w * C0[c] - mc + theta + nu, pm, dd, cc, s1);
+                pc = theta + gam * (dd - cc);
+            } else if (lin[c]) {
+                const double q0 = D0[c] - C0[c], theta = lp0[c] - lkap[c] * q0;
+                box2(w + lkap[c], lkap[c], lia[c], lidet[c], ls2[c], w * D0[c] - mc - theta - nu, w * C0[c] - mc + theta + nu,
+                     pm, dd, cc, s1);
+                pc = theta + lkap[c] * (dd - cc);
+            } else {
+                const TabRef tb = tab_ref(v, it.node, tbase + c);
+                eval_lines(tb, hint[c], w, iw, mc, pm, D0[c], C0[c], nu, dd, cc, s1, pc);
+            }
+        };
+        // previous level trajectory -> contacts
         const double inclE = scan_sum<LPS>(run, lane);
         const double prevE = prev_lane<LPS>(inclE);
         double eo = li == 0 ? 0.0 : prevE;
         const double tolc = 1e-9 * (1.0 + em), tolE = 1e-11 * (1.0 + em), tolr = 1e-12 * (1.0 + em);
         int kind[NCH];                       // 0 free, 1 empty, 2 full
-        bool isend[NCH];
-        double tgt[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int t = tbase + c;
             eo += C0[c] - D0[c];
             kind[c] = t < T ? (eo <= tolc ? 1 : (eo >= em - tolc ? 2 : 0)) : 0;
-            isend[c] = t < T && (kind[c] != 0 || t == T - 1);
-            tgt[c] = kind[c] == 2 ? em : 0.0;
-            key[t] = isend[c] ? t : (t >= T ? T - 1 : 0x3fffffff);
         }
-        __builtin_amdgcn_wave_barrier();
-        for (int d = 1; d < TP; d <<= 1) {     // next segment end at or after t (pointer jumping in LDS)
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int t = tbase + c;
-                if (t + d < TP) { const int o = key[t + d], m0 = key[t]; key[t] = o < m0 ? o : m0; }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        int send[NCH];
-        bool st[NCH];
-        // info of the step before this lane's first step: target level if it is a segment end, else -1
-        const double lastInfo = isend[NCH - 1] ? tgt[NCH - 1] : -1.0;
-        const double plInfo = prev_lane<LPS>(lastInfo);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int t = tbase + c;
-            send[c] = key[t < TP ? t : TP - 1];
-            double pinfo;
-            if (c == 0) pinfo = li == 0 ? 0.0 : plInfo;
-            else pinfo = isend[c - 1] ? tgt[c - 1] : -1.0;
-            st[c] = t < T && pinfo >= 0.0;
-            if (st[c]) base[send[c]] = pinfo;                  // level at which this segment starts
-            if (isend[c]) nuL[t] = kind[c] != 0 ? nuv[c] : 0.0; // one price per segment; open last segment: 0
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) nuv[c] = (tbase + c < T) ? nuL[send[c]] : 0.0;
 
-        // ---- segmented Newton ---------------------------------------------------------------------
-        double Dv[NCH], Cv[NCH], px[NCH], ps[NCH];
-        bool conv = false;
-        for (int itn = 0; itn < 8; ++itn) {
-            double sg[NCH];
-            int f = 0;
-            double rx = 0.0, rs = 0.0;
-            bool seen[NCH];
+        bool gdone = !live, good = false;
+        for (int round = 0; round < MAXR; ++round) {
+#ifdef DOPF_STATS
+            if (li == 0 && !gdone) ++st_rounds;
+#endif
+            // ---- A. segments of the current contact set --------------------------------------------------
+            bool isend[NCH], st[NCH];
+            double tgt[NCH], bs[NCH];
+            int send[NCH];
+            int mfirst = BIG;
+#pragma unroll
+            for (int c = NCH - 1; c >= 0; --c) {
+                const int t = tbase + c;
+                isend[c] = t < T && (kind[c] != 0 || t == T - 1);
+                tgt[c] = kind[c] == 2 ? em : 0.0;
+                if (isend[c]) mfirst = t;
+            }
+            {
+                const int incl = scan_min_rev_i<LPS>(mfirst, lane);
+                const int nxt = next_lane_i<LPS>(incl);
+                int carry = li == LPS - 1 ? BIG : nxt;       // first segment end in the lanes to the right
+#pragma unroll
+                for (int c = NCH - 1; c >= 0; --c) {
+                    if (isend[c]) carry = tbase + c;
+                    send[c] = carry < TP ? carry : TP - 1;   // (steps past the horizon: any valid slot)
+                }
+            }
+            // info of the step before this lane's first step: target level if it is a segment end, else -1
+            const double lastInfo = isend[NCH - 1] ? tgt[NCH - 1] : -1.0;
+            const double plInfo = prev_lane<LPS>(lastInfo);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int t = tbase + c;
-                double dd = 0.0, cc = 0.0, s1 = 0.0;
-                if (t < T) {
-                    if (!LINES) {
-                        const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
-                        box2(a0, gam, ia0, idet0, s20, w * D0[c] - mc - theta - nuv[c], w * C0[c] - mc + theta + nuv[c], pm, dd, cc, s1);
-                    } else if (lin[c]) {
-                        const double q0 = D0[c] - C0[c], theta = lp0[c] - lkap[c] * q0;
-                        box2(w + lkap[c], lkap[c], lia[c], lidet[c], ls2[c], w * D0[c] - mc - theta - nuv[c], w * C0[c] - mc + theta + nuv[c],
-                             pm, dd, cc, s1);
-                    } else {
-                        const TabRef tb = tab_ref(v, it.node, t);
-                        double pcx;
-                        eval_lines(tb, hint[c], w, iw, mc, pm, D0[c], C0[c], nuv[c], dd, cc, s1, pcx);
-                    }
-                }
-                Dv[c] = dd; Cv[c] = cc; sg[c] = s1;
-                if (st[c]) { rx = 0.0; rs = 0.0; f = 1; }
-                rx += cc - dd; rs += s1;
-                px[c] = rx; ps[c] = rs;
-                seen[c] = f != 0;
+                double pinfo;
+                if (c == 0) pinfo = li == 0 ? 0.0 : plInfo;
+                else pinfo = isend[c - 1] ? tgt[c - 1] : -1.0;
+                st[c] = t < T && pinfo >= 0.0;
+                if (st[c]) base[send[c]] = pinfo;                  // level at which this segment starts
+                if (isend[c]) nuL[t] = kind[c] != 0 ? nuv[c] : 0.0; // one price per segment; open last segment: 0
             }
-            int fl = f;
-            double ax = rx, as = rs;
-            seg_scan2<LPS>(fl, ax, as, lane);
-            double cx = prev_lane<LPS>(ax), cs = prev_lane<LPS>(as);
-            if (li == 0) { cx = 0.0; cs = 0.0; }
-            double worst = 0.0;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int t = tbase + c;
-                if (!seen[c]) { px[c] += cx; ps[c] += cs; }
-                if (isend[c] && kind[c] != 0) {
-                    const double r = base[t] + px[c] - tgt[c];
-                    const double ar = fabs(r);
-                    if (ar > tolr) {
-                        if (ps[c] > 0.0) nuL[t] = nuv[c] - r / ps[c];
-                        else worst = INFINITY;            // flat piece: leave it to the scan kernel
-                    }
-                    worst = fmax(worst, ar);
-                }
-            }
-            worst = group_max<LPS>(worst);
-            if (worst <= tolr) { conv = true; }
-            if (!(worst < INFINITY)) { conv = false; }
-            // every group in the wave runs the same number of rounds (DPP scans need all lanes)
-            if (__all(conv || !(worst < INFINITY) || !good)) break;
             __builtin_amdgcn_wave_barrier();
-            if (!conv) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const bool ok = tbase + c < T;
+                nuv[c] = ok ? nuL[send[c]] : 0.0;
+                bs[c] = ok ? base[send[c]] : 0.0;
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- B. segmented Newton, bracketed --------------------------------------------------------------
+            double Dv[NCH], Cv[NCH], px[NCH], ps[NCH], blo[NCH], bhi[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { blo[c] = -INFINITY; bhi[c] = INFINITY; }
+            bool nconv = false, nfail = false;
+            for (int itn = 0; itn < MAXN; ++itn) {
+#ifdef DOPF_STATS
+                if (li == 0 && !gdone) ++st_newton;
+#endif
+                double psc[NCH];
+                int f = 0;
+                double rx = 0.0, rs = 0.0;
+                bool seen[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int t = tbase + c;
+                    double dd = 0.0, cc = 0.0, s1 = 0.0, pc = 0.0;
+                    if (t < T) eval(c, nuv[c], dd, cc, s1, pc);
+                    Dv[c] = dd; Cv[c] = cc; psc[c] = pc;
+                    if (st[c]) { rx = 0.0; rs = 0.0; f = 1; }
+                    rx += cc - dd; rs += s1;
+                    px[c] = rx; ps[c] = rs;
+                    seen[c] = f != 0;
+                }
+                {
+                    int fl = f;
+                    double ax = rx, as = rs;
+                    seg_scan2<LPS>(fl, ax, as, lane);
+                    double cx = prev_lane<LPS>(ax), cs = prev_lane<LPS>(as);
+                    if (li == 0) { cx = 0.0; cs = 0.0; }
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c)
+                        if (!seen[c]) { px[c] += cx; ps[c] += cs; }
+                }
+                // residual of each segment at its end; does a segment that has to move sit on a flat piece?
+                double rres[NCH];
+                bool flatNeed = false;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    rres[c] = 0.0;
+                    if (isend[c] && kind[c] != 0) {
+                        rres[c] = bs[c] + px[c] - tgt[c];
+                        if (fabs(rres[c]) > tolr && !(ps[c] > 0.0)) flatNeed = true;
+                    }
+                }
+                // flat piece: every step of the segment has D and C on bounds, its net injection (hence Psi) does not
+                // move with nu and the four prices at which D or C would leave a bound are closed form: distance to
+                // the nearest one above / below, per segment
+                double fup[NCH], fdn[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) { fup[c] = INFINITY; fdn[c] = INFINITY; }
+                if (__any(flatNeed && !gdone)) {
+                    int f2 = 0;
+                    double ru = -INFINITY, rd = INFINITY;        // (-min distance above, min distance below) so far
+                    bool seen2[NCH];
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        double du = INFINITY, dn = INFINITY;
+                        if (tbase + c < T) {
+                            const double bD = w * D0[c] - mc - psc[c], bC = mc - w * C0[c] - psc[c], wp = w * pm;
+                            const double cand[4] = {bD, bD - wp, bC, bC + wp};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const double d = cand[q] - nuv[c];
+                                if (d > 0.0) du = fmin(du, d);
+                                if (d < 0.0) dn = fmin(dn, -d);
+                            }
+                        }
+                        if (st[c]) { ru = -INFINITY; rd = INFINITY; f2 = 1; }
+                        ru = fmax(ru, -du); rd = fmin(rd, dn);
+                        fup[c] = ru; fdn[c] = rd;
+                        seen2[c] = f2 != 0;
+                    }
+                    int fl = f2;
+                    double au = ru, ad = rd;
+                    seg_scan_maxmin<LPS>(fl, au, ad, lane);
+                    double cu = prev_lane<LPS>(au), cd = prev_lane<LPS>(ad);
+                    if (li == 0) { cu = -INFINITY; cd = INFINITY; }
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        if (!seen2[c]) { fup[c] = fmax(fup[c], cu); fdn[c] = fmin(fdn[c], cd); }
+                        fup[c] = -fup[c];
+                    }
+                }
+                double worst = 0.0;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int t = tbase + c;
+                    if (isend[c] && kind[c] != 0) {
+                        const double r = rres[c];
+                        double ar = fabs(r);
+                        if (ar > tolr) {
+                            const double nu = nuv[c];
+                            if (r < 0.0) blo[c] = nu; else bhi[c] = nu;
+                            const bool both = blo[c] > -INFINITY && bhi[c] < INFINITY;
+                            double trial;
+                            if (ps[c] > 0.0) {
+                                trial = nu - r / ps[c];
+                            } else {
+                                const double dist = r < 0.0 ? fup[c] : fdn[c];
+                                const double dir = r < 0.0 ? 1.0 : -1.0;
+                                trial = nu + dir * (dist + 1e-9 * (1.0 + fabs(nu) + dist));      // (inf when no kink lies ahead)
+                            }
+                            if (!(trial > blo[c] && trial < bhi[c]) || (both && itn >= 8 && (itn & 1))) {
+                                if (both) trial = 0.5 * (blo[c] + bhi[c]);
+                            }
+                            if (trial > blo[c] && trial < bhi[c]) nuL[t] = trial;
+                            else if (both) ar = 0.0;           // bracket is two adjacent doubles: this is the root
+                            else nfail = true;                 // nothing ahead moves this segment: not a valid contact set
+                        }
+                        worst = fmax(worst, ar);
+                    }
+                }
+                worst = group_max<LPS>(worst);
+                nfail = group_bits<LPS>(nfail, gbase) != 0ull;
+                nconv = worst <= tolr && !nfail;
+                // every group in the wave runs the same number of rounds (DPP scans need all lanes)
+                if (__all(gdone || nconv || nfail)) break;
+                __builtin_amdgcn_wave_barrier();
+                if (!nconv) {
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c)
+                        if (tbase + c < T) nuv[c] = nuL[send[c]];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+
+            // ---- C. certificate: levels inside the band, price jumps have the right sign ----------------------
+            // A contact step that is a segment of its own with zero net charge (the storage idles on a bound)
+            // accepts every price of its dead band [rD0, -rC0]; all other segment prices are points. Prices
+            // are then chosen right to left, nu_e = clamp(nu_next, band_e) starting from nu_{T+1} = 0 — the
+            // choice that satisfies the sign condition at e whenever any does — with one suffix scan of
+            // clamp maps, and the sign conditions are checked on that choice.
+            bool okk = true;
+            int nkind[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) nkind[c] = kind[c];
+            // Copper plate: a segment whose steps ALL sit on a corner of their (D, C) box (charging or discharging at
+            // full rate, or idle) does not move with its price: every price in the intersection of the steps' corner
+            // intervals is a multiplier of that segment, not just the one Newton happened to stop at. With
+            // grad_D = a D - gam C - (rD0 - nu), grad_C = a C - gam D - (rC0 + nu):
+            //   D = 0: nu >= rD0 + gam C      D = pm: nu <= rD0 - a pm + gam C
+            //   C = 0: nu <= -rC0 - gam D     C = pm: nu >= a pm - gam D - rC0
+            double slo[NCH], shi[NCH];
+            if (!LINES) {
+                int f = 0;
+                double rl = -INFINITY, rh = INFINITY;
+                bool seen[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int t = tbase + c;
+                    double lo = -INFINITY, hi = INFINITY;
+                    if (t < T) {
+                        const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
+                        const double rD0 = w * D0[c] - mc - theta, rC0 = w * C0[c] - mc + theta;
+                        const double dd = Dv[c], cc = Cv[c];
+                        if (dd <= 0.0) lo = rD0 + gam * cc; else if (dd >= pm) hi = rD0 - a0 * pm + gam * cc;
+                        if (cc <= 0.0) hi = fmin(hi, -rC0 - gam * dd); else if (cc >= pm) lo = fmax(lo, a0 * pm - gam * dd - rC0);
+                    }
+                    if (st[c]) { rl = -INFINITY; rh = INFINITY; f = 1; }
+                    rl = fmax(rl, lo); rh = fmin(rh, hi);
+                    slo[c] = rl; shi[c] = rh;
+                    seen[c] = f != 0;
+                }
+                int fl = f;
+                double al = rl, ah = rh;
+                seg_scan_maxmin<LPS>(fl, al, ah, lane);
+                double cl = prev_lane<LPS>(al), ch = prev_lane<LPS>(ah);
+                if (li == 0) { cl = -INFINITY; ch = INFINITY; }
 #pragma unroll
                 for (int c = 0; c < NCH; ++c)
-                    if (tbase + c < T) nuv[c] = nuL[send[c]];
+                    if (!seen[c]) { slo[c] = fmax(slo[c], cl); shi[c] = fmin(shi[c], ch); }
+            }
+            double Ev[NCH], mlo[NCH], mhi[NCH];
+            // Prices: segment i (ending at contact e_i) may take any nu_i in [mlo, mhi] (a point unless the segment is
+            // flat); an empty contact needs nu_i >= nu_{i+1}, a full one nu_i <= nu_{i+1}, and nu past the horizon is 0.
+            // Right to left, the set of nu_i that can be completed to the right is the interval
+            //   empty: [max(mlo, flo_{i+1}), mhi]      full: [mlo, min(mhi, fhi_{i+1})]      open last segment: {0}
+            // — two chains of clamp maps (one for the lower ends, one for the upper ends), one suffix scan each;
+            // the certificate holds iff no interval is empty.
+            double alo = -INFINITY, ahi = INFINITY, blo2 = -INFINITY, bhi2 = INFINITY;      // this lane's composed maps
+#pragma unroll
+            for (int c = NCH - 1; c >= 0; --c) {
+                const int t = tbase + c;
+                mlo[c] = -INFINITY; mhi[c] = INFINITY;
+                Ev[c] = 0.0;
+                if (t < T) {
+                    Ev[c] = bs[c] + px[c];
+                    if (!(isend[c] && kind[c] != 0)) {           // (a contact's level is its Newton target)
+                        if (Ev[c] < -tolE) { okk = false; nkind[c] = 1; }
+                        else if (Ev[c] > em + tolE) { okk = false; nkind[c] = 2; }
+                    }
+                    if (isend[c]) {
+                        mlo[c] = mhi[c] = kind[c] != 0 ? nuv[c] : 0.0;
+                        if (!LINES) {
+                            // flat segment (zero slope at its end = every step on a corner): the whole interval
+                            if (kind[c] != 0 && ps[c] == 0.0 && slo[c] <= shi[c] && nuv[c] >= slo[c] - 1e-9 && nuv[c] <= shi[c] + 1e-9) {
+                                mlo[c] = slo[c]; mhi[c] = shi[c];
+                            }
+                        } else if (kind[c] != 0 && st[c] && bs[c] == tgt[c]) {
+                            // idle on a bound: with D = C = 0 the step's net injection is unchanged at q = 0: dlt = -q0
+                            const double q0 = D0[c] - C0[c];
+                            const double theta = lin[c] ? lp0[c] - lkap[c] * q0 : tab_psi_at(tab_ref(v, it.node, t), -q0);
+                            const double rD0 = w * D0[c] - mc - theta, rC0 = w * C0[c] - mc + theta;
+                            if (rD0 <= -rC0 && nuv[c] >= rD0 - 1e-9 && nuv[c] <= -rC0 + 1e-9) { mlo[c] = rD0; mhi[c] = -rC0; }
+                        }
+                        // lower-end chain: empty x -> max(mlo, x), full/open x -> mlo; upper-end chain: empty/open x -> mhi, full x -> min(mhi, x)
+                        const double a_lo = mlo[c], a_hi = kind[c] == 1 ? INFINITY : mlo[c];
+                        const double b_lo = kind[c] == 2 ? -INFINITY : mhi[c], b_hi = mhi[c];
+                        const double nal = clampd(alo, a_lo, a_hi), nah = clampd(ahi, a_lo, a_hi);
+                        const double nbl = clampd(blo2, b_lo, b_hi), nbh = clampd(bhi2, b_lo, b_hi);
+                        alo = nal; ahi = nah; blo2 = nbl; bhi2 = nbh;
+                    }
+                }
+            }
+            scan_clamps_rev<LPS>(alo, ahi, lane);
+            scan_clamps_rev<LPS>(blo2, bhi2, lane);
+            // ends of the feasible interval arriving from the right of this lane: (lanes to the right)(0)
+            const double rightA = next_lane<LPS>(clampd(0.0, alo, ahi)), rightB = next_lane<LPS>(clampd(0.0, blo2, bhi2));
+            double flo = li == LPS - 1 ? 0.0 : rightA, fhi = li == LPS - 1 ? 0.0 : rightB;
+            double nuc[NCH];                                     // the certified prices (move only inside a flat segment's interval)
+#pragma unroll
+            for (int c = NCH - 1; c >= 0; --c) {
+                const int t = tbase + c;
+                nuc[c] = nuv[c];
+                if (t < T && isend[c]) {
+                    flo = kind[c] == 1 ? fmax(mlo[c], flo) : mlo[c];
+                    fhi = kind[c] == 2 ? fmin(mhi[c], fhi) : mhi[c];
+                    if (kind[c] != 0) {
+                        const double tn = 1e-10 * (1.0 + fmin(fabs(flo), fabs(fhi)));
+                        if (flo > fhi + tn) { okk = false; nkind[c] = 0; }      // wrong sign: release the contact
+                        nuc[c] = clampd(nuv[c], flo, fmax(flo, fhi));
+                    }
+                }
+            }
+            const bool cert = nconv && group_bits<LPS>(!okk, gbase) == 0ull;
+            bool chg = false;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) chg = chg || nkind[c] != kind[c];
+            const bool changed = group_bits<LPS>(chg, gbase) != 0ull;
+
+            // ---- D. accept, repair the contact set, or give up --------------------------------------------------
+            if (!gdone && cert) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int t = tbase + c;
+                    if (t < T) {
+                        const size_t e = (size_t)s * T + t;
+                        v.D[e] = Dv[c];
+                        v.C[e] = Cv[c];
+                        v.E[e] = Ev[c];
+                        v.nu_prev[e] = nuc[c];
+                        if (LINES) v.dltS[e] = (Dv[c] - Cv[c]) - (D0[c] - C0[c]);
+                        accQ[c] += Dv[c] - Cv[c];
+                        accCost += mc * (Dv[c] + Cv[c]);
+                    }
+                }
+                good = true;
+                gdone = true;
+            }
+            if (!gdone && (!nconv || !changed)) gdone = true;       // Newton stalled / nothing to repair: scan kernel
+            if (__all(gdone)) break;
+            if (!gdone) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) kind[c] = nkind[c];
             }
             __builtin_amdgcn_wave_barrier();
         }
-#ifdef DOPF_STATS
-        if (live && li == 0 && !good) atomicAdd(&v.st->dbg_reason[0], 1ull);
-        else if (live && li == 0 && !conv) atomicAdd(&v.st->dbg_reason[1], 1ull);
-#endif
-        good = good && conv;
 
-        // ---- certificate: levels inside the band, price jumps have the right sign ----------------------
-        // A contact step that is a segment of its own with zero net charge (the storage idles on a bound)
-        // accepts every price of its dead band [rD0, -rC0]; all other segment prices are points. Prices
-        // are then chosen right to left, nu_e = clamp(nu_next, band_e) starting from nu_{T+1} = 0 — the
-        // choice that satisfies the sign condition at e whenever any does — with one suffix scan of
-        // clamp maps, and the sign conditions are checked on that choice.
-        bool okk = true;
-#ifdef DOPF_STATS
-        bool okLevel = true;
-#endif
-        // Copper plate: a segment whose steps ALL sit on a corner of their (D, C) box (charging or discharging at
-        // full rate, or idle) does not move with its price: every price in the intersection of the steps' corner
-        // intervals is a multiplier of that segment, not just the one Newton happened to stop at. With
-        // grad_D = a D - gam C - (rD0 - nu), grad_C = a C - gam D - (rC0 + nu):
-        //   D = 0: nu >= rD0 + gam C      D = pm: nu <= rD0 - a pm + gam C
-        //   C = 0: nu <= -rC0 - gam D     C = pm: nu >= a pm - gam D - rC0
-        double slo[NCH], shi[NCH];
-        if (!LINES) {
-            int f = 0;
-            double rl = -INFINITY, rh = INFINITY;
-            bool seen[NCH];
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int t = tbase + c;
-                double lo = -INFINITY, hi = INFINITY;
-                if (t < T) {
-                    const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
-                    const double rD0 = w * D0[c] - mc - theta, rC0 = w * C0[c] - mc + theta;
-                    const double dd = Dv[c], cc = Cv[c];
-                    if (dd <= 0.0) lo = rD0 + gam * cc; else if (dd >= pm) hi = rD0 - a0 * pm + gam * cc;
-                    if (cc <= 0.0) hi = fmin(hi, -rC0 - gam * dd); else if (cc >= pm) lo = fmax(lo, a0 * pm - gam * dd - rC0);
-                }
-                if (st[c]) { rl = -INFINITY; rh = INFINITY; f = 1; }
-                rl = fmax(rl, lo); rh = fmin(rh, hi);
-                slo[c] = rl; shi[c] = rh;
-                seen[c] = f != 0;
-            }
-            int fl = f;
-            double al = rl, ah = rh;
-            seg_scan_maxmin<LPS>(fl, al, ah, lane);
-            double cl = prev_lane<LPS>(al), ch = prev_lane<LPS>(ah);
-            if (li == 0) { cl = -INFINITY; ch = INFINITY; }
-#pragma unroll
-            for (int c = 0; c < NCH; ++c)
-                if (!seen[c]) { slo[c] = fmax(slo[c], cl); shi[c] = fmin(shi[c], ch); }
-        }
-        double Ev[NCH], mlo[NCH], mhi[NCH];
-        // Prices: segment i (ending at contact e_i) may take any nu_i in [mlo, mhi] (a point unless the segment is
-        // flat); an empty contact needs nu_i >= nu_{i+1}, a full one nu_i <= nu_{i+1}, and nu past the horizon is 0.
-        // Right to left, the set of nu_i that can be completed to the right is the interval
-        //   empty: [max(mlo, flo_{i+1}), mhi]      full: [mlo, min(mhi, fhi_{i+1})]      open last segment: {0}
-        // — two chains of clamp maps (one for the lower ends, one for the upper ends), one suffix scan each;
-        // the certificate holds iff no interval is empty.
-        double alo = -INFINITY, ahi = INFINITY, blo = -INFINITY, bhi = INFINITY;      // this lane's composed maps
-#pragma unroll
-        for (int c = NCH - 1; c >= 0; --c) {
-            const int t = tbase + c;
-            mlo[c] = -INFINITY; mhi[c] = INFINITY;
-            Ev[c] = 0.0;
-            if (t < T) {
-                Ev[c] = base[send[c]] + px[c];
-                if (Ev[c] < -tolE || Ev[c] > em + tolE) {
-                    okk = false;
-#ifdef DOPF_STATS
-                    okLevel = false;
-#endif
-                }
-                if (isend[c]) {
-                    mlo[c] = mhi[c] = kind[c] != 0 ? nuv[c] : 0.0;
-                    if (!LINES) {
-                        // flat segment (zero slope at its end = every step on a corner): the whole interval
-                        if (kind[c] != 0 && ps[c] == 0.0 && slo[c] <= shi[c] && nuv[c] >= slo[c] - 1e-9 && nuv[c] <= shi[c] + 1e-9) {
-                            mlo[c] = slo[c]; mhi[c] = shi[c];
-                        }
-                    } else if (kind[c] != 0 && st[c] && base[t] == tgt[c]) {
-                        // idle on a bound: with D = C = 0 the step's net injection is unchanged at q = 0: dlt = -q0
-                        const double q0 = D0[c] - C0[c];
-                        const double theta = lin[c] ? lp0[c] - lkap[c] * q0 : tab_psi_at(tab_ref(v, it.node, t), -q0);
-                        const double rD0 = w * D0[c] - mc - theta, rC0 = w * C0[c] - mc + theta;
-                        if (rD0 <= -rC0 && nuv[c] >= rD0 - 1e-9 && nuv[c] <= -rC0 + 1e-9) { mlo[c] = rD0; mhi[c] = -rC0; }
-                    }
-                    // lower-end chain: empty x -> max(mlo, x), full/open x -> mlo; upper-end chain: empty/open x -> mhi, full x -> min(mhi, x)
-                    const double a_lo = mlo[c], a_hi = kind[c] == 1 ? INFINITY : mlo[c];
-                    const double b_lo = kind[c] == 2 ? -INFINITY : mhi[c], b_hi = mhi[c];
-                    const double nal = clampd(alo, a_lo, a_hi), nah = clampd(ahi, a_lo, a_hi);
-                    const double nbl = clampd(blo, b_lo, b_hi), nbh = clampd(bhi, b_lo, b_hi);
-                    alo = nal; ahi = nah; blo = nbl; bhi = nbh;
-                }
-            }
-        }
-        scan_clamps_rev<LPS>(alo, ahi, lane);
-        scan_clamps_rev<LPS>(blo, bhi, lane);
-        // ends of the feasible interval arriving from the right of this lane: (lanes to the right)(0)
-        const double rightA = next_lane<LPS>(clampd(0.0, alo, ahi)), rightB = next_lane<LPS>(clampd(0.0, blo, bhi));
-        double flo = li == LPS - 1 ? 0.0 : rightA, fhi = li == LPS - 1 ? 0.0 : rightB;
-#pragma unroll
-        for (int c = NCH - 1; c >= 0; --c) {
-            const int t = tbase + c;
-            if (t < T && isend[c]) {
-                flo = kind[c] == 1 ? fmax(mlo[c], flo) : mlo[c];
-                fhi = kind[c] == 2 ? fmin(mhi[c], fhi) : mhi[c];
-                if (kind[c] != 0) {
-                    const double tn = 1e-10 * (1.0 + fmin(fabs(flo), fabs(fhi)));
-                    if (flo > fhi + tn) okk = false;
-                    nuv[c] = clampd(nuv[c], flo, fmax(flo, fhi));      // (moves only inside a flat segment's interval)
-                }
-            }
-        }
-#ifdef DOPF_STATS
-        {
-            const bool lv = group_bits<LPS>(!okLevel, lane & ~(LPS - 1)) != 0ull, an = group_bits<LPS>(!okk, lane & ~(LPS - 1)) != 0ull;
-            if (live && li == 0 && good && lv) atomicAdd(&v.st->dbg_reason[2], 1ull);
-            else if (live && li == 0 && good && an) atomicAdd(&v.st->dbg_reason[3], 1ull);
-        }
-#endif
-        good = good && (group_bits<LPS>(!okk, lane & ~(LPS - 1)) == 0ull);
-
-        if (live && li == 0) v.sto_fail[s] = good ? 0 : 1;
+        if (live && li == 0) { v.sto_fail[s] = good ? 0 : 1; if (good) v.nu_valid[s] = 1; }
         if (live && !good && li == 0) anyFail += 1;
-        if (good) {
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int t = tbase + c;
-                if (t < T) {
-                    const size_t e = (size_t)s * T + t;
-                    v.D[e] = Dv[c];
-                    v.C[e] = Cv[c];
-                    v.E[e] = Ev[c];
-                    v.nu_prev[e] = nuv[c];
-                    if (LINES) v.dltS[e] = (Dv[c] - Cv[c]) - (D0[c] - C0[c]);
-                    accQ[c] += Dv[c] - Cv[c];
-                    accCost += mc * (Dv[c] + Cv[c]);
-                }
-            }
-        }
         __builtin_amdgcn_wave_barrier();
     }
+#ifdef DOPF_STATS
+    if (st_rounds) atomicAdd(&v.st->dbg_reason[0], st_rounds);
+    if (st_newton) atomicAdd(&v.st->dbg_reason[1], st_newton);
+#endif
 
     // fixed-order block reduction of the per-timestep sums over the NG groups
     __syncthreads();
