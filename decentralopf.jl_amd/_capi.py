@@ -241,7 +241,7 @@ class Engine:
 
     def warm_start_stats(self):
         """(storages the warm-start kernel solved, storages it left to the scan kernel) in the LAST iteration."""
-        out = (C.c_uint64 * 9)()
+        out = (C.c_uint64 * 15)()
         self._chk(self.api.debug_stats(self._ctx, out))
         return int(out[3]), int(out[4])
 

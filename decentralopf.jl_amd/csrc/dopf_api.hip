@@ -694,7 +694,7 @@ int dopf_debug_table(dopf_ctx *c, int32_t n, int32_t t, double *beta, double *ps
 }
 
 // diagnostics (DOPF_STATS builds): cumulative storage-kernel counters {scans, wave loop trips, events}
-int dopf_debug_stats(dopf_ctx *c, uint64_t *out3 /* 9 values */)
+int dopf_debug_stats(dopf_ctx *c, uint64_t *out3 /* 15 values */)
 {
     if (!c || !out3) return DOPF_E_INVALID;
     DeviceGuard guard(c->device);
@@ -710,6 +710,7 @@ int dopf_debug_stats(dopf_ctx *c, uint64_t *out3 /* 9 values */)
         out3[3] = (uint64_t)c->v.S - out3[4];
     }
     for (int i = 0; i < 4; ++i) out3[5 + i] = c->host_st.dbg_reason[i];
+    for (int i = 0; i < 6; ++i) out3[9 + i] = c->host_st.dbg_cyc[i];
     return DOPF_OK;
 }
 

@@ -34,6 +34,7 @@ struct Status {
     int iters_total;        // iterations computed since creation
     unsigned long long solver_fail;
     unsigned long long dbg_scans, dbg_wave_loops, dbg_events;   // storage kernel statistics (DOPF_STATS builds)
+    unsigned long long dbg_cyc[6];                              // DOPF_STATS: wave cycles per section of the storage body
     unsigned long long dbg_reason[4];                           // DOPF_STATS: no prices / Newton / level / sign
     unsigned long long resbits[3];   // running max of |dual change| as bit patterns (>= 0 doubles)
     double res[3];          // lambda / mu / rho residual inf-norms of the last checked iteration

@@ -958,8 +958,11 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
     constexpr int MAXR = 16;                 // contact-set rounds per storage
     constexpr int MAXN = 40;                 // Newton iterations per round
     constexpr int BIG = 0x3fffffff;
-    __shared__ double red[NG * TP];          // also nuL during the solve
-    __shared__ double baseL[NG * TP];
+    // per lane group, indexed by timestep; the last three only at segment ends
+    __shared__ double red[NG * TP];          // nuL: price of the segment that ends here (also the final reduction's buffer)
+    __shared__ double baseL[NG * TP];        // level at which the segment that ends here starts
+    __shared__ double loL[NG * TP], hiL[NG * TP];    // Newton bracket of the segment's price
+    __shared__ double fdL[NG * TP];          // flat segment: signed distance to the nearest kink ahead
     __shared__ double redc[256];
     const int tid = threadIdx.x, lane = tid & 63, li = tid & (LPS - 1), grp = tid / LPS;
     const int gbase = lane & ~(LPS - 1);
@@ -968,7 +971,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
     const double w = v.w_prox, gam = v.gamma;
     const double a0 = w + gam, ia0 = 1.0 / a0, idet0 = 1.0 / (a0 * a0 - gam * gam), s20 = 2.0 / (a0 + gam);
     const int tbase = li * NCH;
-    double *nuL = red + grp * TP, *base = baseL + grp * TP;
+    double *nuL = red + grp * TP, *base = baseL + grp * TP, *lo_ = loL + grp * TP, *hi_ = hiL + grp * TP, *fd_ = fdL + grp * TP;
 
     double th0[NCH], accQ[NCH];
     double accCost = 0.0;
@@ -999,7 +1002,12 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
         }
     }
 #ifdef DOPF_STATS
-    unsigned long long st_rounds = 0, st_newton = 0;
+    unsigned long long st_rounds = 0, st_newton = 0, cyc[6] = {0, 0, 0, 0, 0, 0}, tq = 0;
+#define DOPF_TIC() tq = clock64()
+#define DOPF_TOC(i) { const unsigned long long t2_ = clock64(); cyc[i] += t2_ - tq; tq = t2_; }
+#else
+#define DOPF_TIC()
+#define DOPF_TOC(i)
 #endif
     const int nRep = (it.a1 - it.a0 + NG - 1) / NG;
     for (int rep = 0; rep < nRep; ++rep) {
@@ -1007,7 +1015,9 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
         const bool live = s < it.a1;
         const double mc = live ? v.sto_mc[s] : 0.0, pm = live ? v.sto_pmax[s] : 0.0, em = live ? v.sto_emax[s] : 0.0;
         const bool havenu = live && v.nu_valid[s] != 0;
-        double D0[NCH], C0[NCH], nuv[NCH];
+        // copper plate: the nu-independent parts of the two gradient offsets, rD = rD0 - nu, rC = rC0 + nu
+        // (with lines Psi depends on the step itself: D0/C0 are kept and the offsets are built per evaluation)
+        double A0[NCH], B0[NCH], nuv[NCH];       // (rD0, rC0) without lines, (D0, C0) with
         int hint[NCH];
         const double iw = 1.0 / w;
         double run = 0.0;
@@ -1016,39 +1026,59 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
             const int t = tbase + c;
             const bool ok = live && t < T;
             const size_t e = (size_t)s * T + (ok ? t : 0);
-            D0[c] = ok ? v.D[e] : 0.0;
-            C0[c] = ok ? v.C[e] : 0.0;
+            const double d0 = ok ? v.D[e] : 0.0, c0 = ok ? v.C[e] : 0.0;
             nuv[c] = (ok && havenu) ? v.nu_prev[e] : 0.0;      // no stored prices (zero state, set_state): start from 0
             hint[c] = 0;
-            run += C0[c] - D0[c];
+            run += c0 - d0;
+            if (LINES) { A0[c] = d0; B0[c] = c0; }
+            else {
+                const double theta = th0[c] - gam * (d0 - c0);
+                A0[c] = w * d0 - mc - theta; B0[c] = w * c0 - mc + theta;
+            }
         }
-        // (D, C)(nu) of step c, d(C - D)/dnu, Psi at the step's net injection
-        auto eval = [&](int c, double nu, double &dd, double &cc, double &s1, double &pc) {
+        // (D, C)(nu) of step c, d(C - D)/dnu; shift = Psi at the step's net injection minus its nu-independent anchor
+        auto eval = [&](int c, double nu, double &dd, double &cc, double &s1) {
             if (!LINES) {
-                const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
-                box2(a0, gam, ia0, idet0, s20, w * D0[c] - mc - theta - nu, w * C0[c] - mc + theta + nu, pm, dd, cc, s1);
-                pc = theta + gam * (dd - cc);
+                box2(a0, gam, ia0, idet0, s20, A0[c] - nu, B0[c] + nu, pm, dd, cc, s1);
             } else if (lin[c]) {
-                const double q0 = D0[c] - C0[c], theta = lp0[c] - lkap[c] * q0;
-                box2(w + lkap[c], lkap[c], lia[c], lidet[c], ls2[c], w * D0[c] - mc - theta - nu, w * C0[c] - mc + theta + nu,
+                const double q0 = A0[c] - B0[c], theta = lp0[c] - lkap[c] * q0;
+                box2(w + lkap[c], lkap[c], lia[c], lidet[c], ls2[c], w * A0[c] - mc - theta - nu, w * B0[c] - mc + theta + nu,
                      pm, dd, cc, s1);
-                pc = theta + lkap[c] * (dd - cc);
             } else {
+                double pc;
                 const TabRef tb = tab_ref(v, it.node, tbase + c);
-                eval_lines(tb, hint[c], w, iw, mc, pm, D0[c], C0[c], nu, dd, cc, s1, pc);
+                eval_lines(tb, hint[c], w, iw, mc, pm, A0[c], B0[c], nu, dd, cc, s1, pc);
+            }
+        };
+        // the four prices at which D or C of step c would leave a bound with the step's net injection (hence Psi)
+        // frozen at (dd, cc): bD, bD - w pm, bC, bC + w pm
+        auto kinks = [&](int c, double dd, double cc, double &bD, double &bC) {
+            if (!LINES) {
+                bD = A0[c] - gam * (dd - cc); bC = -B0[c] - gam * (dd - cc);
+            } else {
+                double pc;
+                if (lin[c]) pc = lp0[c] + lkap[c] * ((dd - cc) - (A0[c] - B0[c]));
+                else pc = tab_psi_at(tab_ref(v, it.node, tbase + c), (dd - cc) - (A0[c] - B0[c]));
+                bD = w * A0[c] - mc - pc; bC = mc - w * B0[c] - pc;
             }
         };
         // previous level trajectory -> contacts
         const double inclE = scan_sum<LPS>(run, lane);
         const double prevE = prev_lane<LPS>(inclE);
-        double eo = li == 0 ? 0.0 : prevE;
         const double tolc = 1e-9 * (1.0 + em), tolE = 1e-11 * (1.0 + em), tolr = 1e-12 * (1.0 + em);
         int kind[NCH];                       // 0 free, 1 empty, 2 full
+        // (levels need D0, C0 themselves: re-read them — L1 hits — instead of keeping two more arrays alive)
+        {
+            double eo = li == 0 ? 0.0 : prevE;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int t = tbase + c;
-            eo += C0[c] - D0[c];
-            kind[c] = t < T ? (eo <= tolc ? 1 : (eo >= em - tolc ? 2 : 0)) : 0;
+            for (int c = 0; c < NCH; ++c) {
+                const int t = tbase + c;
+                const bool ok = live && t < T;
+                const size_t e = (size_t)s * T + (ok ? t : 0);
+                const double d0 = LINES ? A0[c] : (ok ? v.D[e] : 0.0), c0 = LINES ? B0[c] : (ok ? v.C[e] : 0.0);
+                eo += c0 - d0;
+                kind[c] = t < T ? (eo <= tolc ? 1 : (eo >= em - tolc ? 2 : 0)) : 0;
+            }
         }
 
         bool gdone = !live, good = false;
@@ -1057,109 +1087,102 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
             if (li == 0 && !gdone) ++st_rounds;
 #endif
             // ---- A. segments of the current contact set --------------------------------------------------
-            bool isend[NCH], st[NCH];
-            double tgt[NCH], bs[NCH];
+            DOPF_TIC();
+            // end of a segment: a contact, or the last step; start: the step after an end (or step 0)
+#define ISEND(c) (tbase + (c) < T && (kind[c] != 0 || tbase + (c) == T - 1))
+#define TGT(c) (kind[c] == 2 ? em : 0.0)
+            double bs[NCH];
             int send[NCH];
-            int mfirst = BIG;
-#pragma unroll
-            for (int c = NCH - 1; c >= 0; --c) {
-                const int t = tbase + c;
-                isend[c] = t < T && (kind[c] != 0 || t == T - 1);
-                tgt[c] = kind[c] == 2 ? em : 0.0;
-                if (isend[c]) mfirst = t;
-            }
+            bool st0;                                            // this lane's first step starts a segment
             {
+                int mfirst = BIG;
+#pragma unroll
+                for (int c = NCH - 1; c >= 0; --c)
+                    if (ISEND(c)) mfirst = tbase + c;
                 const int incl = scan_min_rev_i<LPS>(mfirst, lane);
                 const int nxt = next_lane_i<LPS>(incl);
                 int carry = li == LPS - 1 ? BIG : nxt;       // first segment end in the lanes to the right
 #pragma unroll
                 for (int c = NCH - 1; c >= 0; --c) {
-                    if (isend[c]) carry = tbase + c;
+                    if (ISEND(c)) carry = tbase + c;
                     send[c] = carry < TP ? carry : TP - 1;   // (steps past the horizon: any valid slot)
                 }
-            }
-            // info of the step before this lane's first step: target level if it is a segment end, else -1
-            const double lastInfo = isend[NCH - 1] ? tgt[NCH - 1] : -1.0;
-            const double plInfo = prev_lane<LPS>(lastInfo);
+                // info of the step before this lane's first step: target level if it is a segment end, else -1
+                const double lastInfo = ISEND(NCH - 1) ? TGT(NCH - 1) : -1.0;
+                const double plInfo = prev_lane<LPS>(lastInfo);
+                st0 = tbase < T && (li == 0 || plInfo >= 0.0);
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int t = tbase + c;
-                double pinfo;
-                if (c == 0) pinfo = li == 0 ? 0.0 : plInfo;
-                else pinfo = isend[c - 1] ? tgt[c - 1] : -1.0;
-                st[c] = t < T && pinfo >= 0.0;
-                if (st[c]) base[send[c]] = pinfo;                  // level at which this segment starts
-                if (isend[c]) nuL[t] = kind[c] != 0 ? nuv[c] : 0.0; // one price per segment; open last segment: 0
-            }
-            __builtin_amdgcn_wave_barrier();
+                for (int c = 0; c < NCH; ++c) {
+                    const int t = tbase + c;
+                    const bool stc = c == 0 ? st0 : (t < T && ISEND(c - 1));
+                    const double pinfo = c == 0 ? (li == 0 ? 0.0 : plInfo) : TGT(c - 1);
+                    if (stc) base[send[c]] = pinfo;                  // level at which this segment starts
+                    if (ISEND(c)) {
+                        nuL[t] = kind[c] != 0 ? nuv[c] : 0.0;        // one price per segment; open last segment: 0
+                        lo_[t] = -INFINITY; hi_[t] = INFINITY;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const bool ok = tbase + c < T;
-                nuv[c] = ok ? nuL[send[c]] : 0.0;
-                bs[c] = ok ? base[send[c]] : 0.0;
+                for (int c = 0; c < NCH; ++c) {
+                    const bool ok = tbase + c < T;
+                    nuv[c] = ok ? nuL[send[c]] : 0.0;
+                    bs[c] = ok ? base[send[c]] : 0.0;
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
+#define STARTS(c) ((c) == 0 ? st0 : (tbase + (c) < T && ISEND((c) - 1)))
 
             // ---- B. segmented Newton, bracketed --------------------------------------------------------------
-            double Dv[NCH], Cv[NCH], px[NCH], ps[NCH], blo[NCH], bhi[NCH];
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) { blo[c] = -INFINITY; bhi[c] = INFINITY; }
+            DOPF_TOC(0)
+            double px[NCH], ps[NCH];
             bool nconv = false, nfail = false;
             for (int itn = 0; itn < MAXN; ++itn) {
 #ifdef DOPF_STATS
                 if (li == 0 && !gdone) ++st_newton;
 #endif
-                double psc[NCH];
-                int f = 0;
-                double rx = 0.0, rs = 0.0;
-                bool seen[NCH];
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const int t = tbase + c;
-                    double dd = 0.0, cc = 0.0, s1 = 0.0, pc = 0.0;
-                    if (t < T) eval(c, nuv[c], dd, cc, s1, pc);
-                    Dv[c] = dd; Cv[c] = cc; psc[c] = pc;
-                    if (st[c]) { rx = 0.0; rs = 0.0; f = 1; }
-                    rx += cc - dd; rs += s1;
-                    px[c] = rx; ps[c] = rs;
-                    seen[c] = f != 0;
-                }
                 {
+                    int f = 0;
+                    double rx = 0.0, rs = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        double dd = 0.0, cc = 0.0, s1 = 0.0;
+                        if (tbase + c < T) eval(c, nuv[c], dd, cc, s1);
+                        if (STARTS(c)) { rx = 0.0; rs = 0.0; f = 1; }
+                        rx += cc - dd; rs += s1;
+                        px[c] = rx; ps[c] = rs;
+                    }
                     int fl = f;
                     double ax = rx, as = rs;
                     seg_scan2<LPS>(fl, ax, as, lane);
                     double cx = prev_lane<LPS>(ax), cs = prev_lane<LPS>(as);
                     if (li == 0) { cx = 0.0; cs = 0.0; }
+                    bool seen = false;
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c)
-                        if (!seen[c]) { px[c] += cx; ps[c] += cs; }
-                }
-                // residual of each segment at its end; does a segment that has to move sit on a flat piece?
-                double rres[NCH];
-                bool flatNeed = false;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    rres[c] = 0.0;
-                    if (isend[c] && kind[c] != 0) {
-                        rres[c] = bs[c] + px[c] - tgt[c];
-                        if (fabs(rres[c]) > tolr && !(ps[c] > 0.0)) flatNeed = true;
+                    for (int c = 0; c < NCH; ++c) {
+                        seen = seen || STARTS(c);
+                        if (!seen) { px[c] += cx; ps[c] += cs; }
                     }
                 }
-                // flat piece: every step of the segment has D and C on bounds, its net injection (hence Psi) does not
-                // move with nu and the four prices at which D or C would leave a bound are closed form: distance to
-                // the nearest one above / below, per segment
-                double fup[NCH], fdn[NCH];
+                // does a segment that has to move sit on a flat piece? Then every step of it has D and C on bounds, its
+                // net injection (hence Psi) does not move with nu and the four prices at which D or C would leave a bound
+                // are closed form: signed distance to the nearest one in the direction the residual asks for
+                bool flatNeed = false;
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) { fup[c] = INFINITY; fdn[c] = INFINITY; }
+                for (int c = 0; c < NCH; ++c)
+                    if (ISEND(c) && kind[c] != 0 && fabs(bs[c] + px[c] - TGT(c)) > tolr && !(ps[c] > 0.0)) flatNeed = true;
                 if (__any(flatNeed && !gdone)) {
                     int f2 = 0;
                     double ru = -INFINITY, rd = INFINITY;        // (-min distance above, min distance below) so far
-                    bool seen2[NCH];
+                    double fu[NCH], fn[NCH];
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) {
                         double du = INFINITY, dn = INFINITY;
                         if (tbase + c < T) {
-                            const double bD = w * D0[c] - mc - psc[c], bC = mc - w * C0[c] - psc[c], wp = w * pm;
+                            double dd, cc, s1, bD, bC;
+                            eval(c, nuv[c], dd, cc, s1);
+                            kinks(c, dd, cc, bD, bC);
+                            const double wp = w * pm;
                             const double cand[4] = {bD, bD - wp, bC, bC + wp};
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
@@ -1168,45 +1191,46 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
                                 if (d < 0.0) dn = fmin(dn, -d);
                             }
                         }
-                        if (st[c]) { ru = -INFINITY; rd = INFINITY; f2 = 1; }
+                        if (STARTS(c)) { ru = -INFINITY; rd = INFINITY; f2 = 1; }
                         ru = fmax(ru, -du); rd = fmin(rd, dn);
-                        fup[c] = ru; fdn[c] = rd;
-                        seen2[c] = f2 != 0;
+                        fu[c] = ru; fn[c] = rd;
                     }
                     int fl = f2;
                     double au = ru, ad = rd;
                     seg_scan_maxmin<LPS>(fl, au, ad, lane);
                     double cu = prev_lane<LPS>(au), cd = prev_lane<LPS>(ad);
                     if (li == 0) { cu = -INFINITY; cd = INFINITY; }
+                    bool seen = false;
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) {
-                        if (!seen2[c]) { fup[c] = fmax(fup[c], cu); fdn[c] = fmin(fdn[c], cd); }
-                        fup[c] = -fup[c];
+                        seen = seen || STARTS(c);
+                        if (!seen) { fu[c] = fmax(fu[c], cu); fn[c] = fmin(fn[c], cd); }
+                        if (ISEND(c) && kind[c] != 0) fd_[tbase + c] = (bs[c] + px[c] - TGT(c)) < 0.0 ? -fu[c] : -fn[c];
                     }
                 }
                 double worst = 0.0;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const int t = tbase + c;
-                    if (isend[c] && kind[c] != 0) {
-                        const double r = rres[c];
+                    if (ISEND(c) && kind[c] != 0) {
+                        const double r = bs[c] + px[c] - TGT(c);
                         double ar = fabs(r);
                         if (ar > tolr) {
                             const double nu = nuv[c];
-                            if (r < 0.0) blo[c] = nu; else bhi[c] = nu;
-                            const bool both = blo[c] > -INFINITY && bhi[c] < INFINITY;
+                            double blo = lo_[t], bhi = hi_[t];
+                            if (r < 0.0) { blo = nu; lo_[t] = nu; } else { bhi = nu; hi_[t] = nu; }
+                            const bool both = blo > -INFINITY && bhi < INFINITY;
                             double trial;
                             if (ps[c] > 0.0) {
                                 trial = nu - r / ps[c];
                             } else {
-                                const double dist = r < 0.0 ? fup[c] : fdn[c];
-                                const double dir = r < 0.0 ? 1.0 : -1.0;
-                                trial = nu + dir * (dist + 1e-9 * (1.0 + fabs(nu) + dist));      // (inf when no kink lies ahead)
+                                const double sd = fd_[t];                  // signed; +-inf when no kink lies ahead
+                                trial = nu + sd + copysign(1e-9 * (1.0 + fabs(nu) + fabs(sd)), sd);
                             }
-                            if (!(trial > blo[c] && trial < bhi[c]) || (both && itn >= 8 && (itn & 1))) {
-                                if (both) trial = 0.5 * (blo[c] + bhi[c]);
+                            if (!(trial > blo && trial < bhi) || (both && itn >= 8 && (itn & 1))) {
+                                if (both) trial = 0.5 * (blo + bhi);
                             }
-                            if (trial > blo[c] && trial < bhi[c]) nuL[t] = trial;
+                            if (trial > blo && trial < bhi) nuL[t] = trial;
                             else if (both) ar = 0.0;           // bracket is two adjacent doubles: this is the root
                             else nfail = true;                 // nothing ahead moves this segment: not a valid contact set
                         }
@@ -1233,10 +1257,17 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
             // are then chosen right to left, nu_e = clamp(nu_next, band_e) starting from nu_{T+1} = 0 — the
             // choice that satisfies the sign condition at e whenever any does — with one suffix scan of
             // clamp maps, and the sign conditions are checked on that choice.
+            DOPF_TOC(1)
             bool okk = true;
             int nkind[NCH];
+            double Dv[NCH], Cv[NCH];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) nkind[c] = kind[c];
+            for (int c = 0; c < NCH; ++c) {
+                nkind[c] = kind[c];
+                double s1;
+                Dv[c] = 0.0; Cv[c] = 0.0;
+                if (tbase + c < T) eval(c, nuv[c], Dv[c], Cv[c], s1);       // (the values px was summed from)
+            }
             // Copper plate: a segment whose steps ALL sit on a corner of their (D, C) box (charging or discharging at
             // full rate, or idle) does not move with its price: every price in the intersection of the steps' corner
             // intervals is a multiplier of that segment, not just the one Newton happened to stop at. With
@@ -1247,33 +1278,33 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
             if (!LINES) {
                 int f = 0;
                 double rl = -INFINITY, rh = INFINITY;
-                bool seen[NCH];
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const int t = tbase + c;
                     double lo = -INFINITY, hi = INFINITY;
                     if (t < T) {
-                        const double q0 = D0[c] - C0[c], theta = th0[c] - gam * q0;
-                        const double rD0 = w * D0[c] - mc - theta, rC0 = w * C0[c] - mc + theta;
+                        const double rD0 = A0[c], rC0 = B0[c];
                         const double dd = Dv[c], cc = Cv[c];
                         if (dd <= 0.0) lo = rD0 + gam * cc; else if (dd >= pm) hi = rD0 - a0 * pm + gam * cc;
                         if (cc <= 0.0) hi = fmin(hi, -rC0 - gam * dd); else if (cc >= pm) lo = fmax(lo, a0 * pm - gam * dd - rC0);
                     }
-                    if (st[c]) { rl = -INFINITY; rh = INFINITY; f = 1; }
+                    if (STARTS(c)) { rl = -INFINITY; rh = INFINITY; f = 1; }
                     rl = fmax(rl, lo); rh = fmin(rh, hi);
                     slo[c] = rl; shi[c] = rh;
-                    seen[c] = f != 0;
                 }
                 int fl = f;
                 double al = rl, ah = rh;
                 seg_scan_maxmin<LPS>(fl, al, ah, lane);
                 double cl = prev_lane<LPS>(al), ch = prev_lane<LPS>(ah);
                 if (li == 0) { cl = -INFINITY; ch = INFINITY; }
+                bool seen = false;
 #pragma unroll
-                for (int c = 0; c < NCH; ++c)
-                    if (!seen[c]) { slo[c] = fmax(slo[c], cl); shi[c] = fmin(shi[c], ch); }
+                for (int c = 0; c < NCH; ++c) {
+                    seen = seen || STARTS(c);
+                    if (!seen) { slo[c] = fmax(slo[c], cl); shi[c] = fmin(shi[c], ch); }
+                }
             }
-            double Ev[NCH], mlo[NCH], mhi[NCH];
+            double mlo[NCH], mhi[NCH];
             // Prices: segment i (ending at contact e_i) may take any nu_i in [mlo, mhi] (a point unless the segment is
             // flat); an empty contact needs nu_i >= nu_{i+1}, a full one nu_i <= nu_{i+1}, and nu past the horizon is 0.
             // Right to left, the set of nu_i that can be completed to the right is the interval
@@ -1285,25 +1316,24 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
             for (int c = NCH - 1; c >= 0; --c) {
                 const int t = tbase + c;
                 mlo[c] = -INFINITY; mhi[c] = INFINITY;
-                Ev[c] = 0.0;
                 if (t < T) {
-                    Ev[c] = bs[c] + px[c];
-                    if (!(isend[c] && kind[c] != 0)) {           // (a contact's level is its Newton target)
-                        if (Ev[c] < -tolE) { okk = false; nkind[c] = 1; }
-                        else if (Ev[c] > em + tolE) { okk = false; nkind[c] = 2; }
+                    const double Ev = bs[c] + px[c];
+                    if (!(ISEND(c) && kind[c] != 0)) {           // (a contact's level is its Newton target)
+                        if (Ev < -tolE) { okk = false; nkind[c] = 1; }
+                        else if (Ev > em + tolE) { okk = false; nkind[c] = 2; }
                     }
-                    if (isend[c]) {
+                    if (ISEND(c)) {
                         mlo[c] = mhi[c] = kind[c] != 0 ? nuv[c] : 0.0;
                         if (!LINES) {
                             // flat segment (zero slope at its end = every step on a corner): the whole interval
                             if (kind[c] != 0 && ps[c] == 0.0 && slo[c] <= shi[c] && nuv[c] >= slo[c] - 1e-9 && nuv[c] <= shi[c] + 1e-9) {
                                 mlo[c] = slo[c]; mhi[c] = shi[c];
                             }
-                        } else if (kind[c] != 0 && st[c] && bs[c] == tgt[c]) {
+                        } else if (kind[c] != 0 && STARTS(c) && bs[c] == TGT(c)) {
                             // idle on a bound: with D = C = 0 the step's net injection is unchanged at q = 0: dlt = -q0
-                            const double q0 = D0[c] - C0[c];
+                            const double q0 = A0[c] - B0[c];
                             const double theta = lin[c] ? lp0[c] - lkap[c] * q0 : tab_psi_at(tab_ref(v, it.node, t), -q0);
-                            const double rD0 = w * D0[c] - mc - theta, rC0 = w * C0[c] - mc + theta;
+                            const double rD0 = w * A0[c] - mc - theta, rC0 = w * B0[c] - mc + theta;
                             if (rD0 <= -rC0 && nuv[c] >= rD0 - 1e-9 && nuv[c] <= -rC0 + 1e-9) { mlo[c] = rD0; mhi[c] = -rC0; }
                         }
                         // lower-end chain: empty x -> max(mlo, x), full/open x -> mlo; upper-end chain: empty/open x -> mhi, full x -> min(mhi, x)
@@ -1325,7 +1355,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
             for (int c = NCH - 1; c >= 0; --c) {
                 const int t = tbase + c;
                 nuc[c] = nuv[c];
-                if (t < T && isend[c]) {
+                if (t < T && ISEND(c)) {
                     flo = kind[c] == 1 ? fmax(mlo[c], flo) : mlo[c];
                     fhi = kind[c] == 2 ? fmin(mhi[c], fhi) : mhi[c];
                     if (kind[c] != 0) {
@@ -1342,6 +1372,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
             const bool changed = group_bits<LPS>(chg, gbase) != 0ull;
 
             // ---- D. accept, repair the contact set, or give up --------------------------------------------------
+            DOPF_TOC(2)
             if (!gdone && cert) {
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
@@ -1350,9 +1381,9 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
                         const size_t e = (size_t)s * T + t;
                         v.D[e] = Dv[c];
                         v.C[e] = Cv[c];
-                        v.E[e] = Ev[c];
+                        v.E[e] = bs[c] + px[c];
                         v.nu_prev[e] = nuc[c];
-                        if (LINES) v.dltS[e] = (Dv[c] - Cv[c]) - (D0[c] - C0[c]);
+                        if (LINES) v.dltS[e] = (Dv[c] - Cv[c]) - (A0[c] - B0[c]);
                         accQ[c] += Dv[c] - Cv[c];
                         accCost += mc * (Dv[c] + Cv[c]);
                     }
@@ -1361,12 +1392,16 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
                 gdone = true;
             }
             if (!gdone && (!nconv || !changed)) gdone = true;       // Newton stalled / nothing to repair: scan kernel
+            DOPF_TOC(3)
             if (__all(gdone)) break;
             if (!gdone) {
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) kind[c] = nkind[c];
             }
             __builtin_amdgcn_wave_barrier();
+#undef ISEND
+#undef TGT
+#undef STARTS
         }
 
         if (live && li == 0) { v.sto_fail[s] = good ? 0 : 1; if (good) v.nu_valid[s] = 1; }
@@ -1376,7 +1411,12 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
 #ifdef DOPF_STATS
     if (st_rounds) atomicAdd(&v.st->dbg_reason[0], st_rounds);
     if (st_newton) atomicAdd(&v.st->dbg_reason[1], st_newton);
+    if (lane == 0) for (int i = 0; i < 6; ++i) atomicAdd(&v.st->dbg_cyc[i], cyc[i]);
+    if (st_rounds) atomicMax(&v.st->dbg_reason[2], st_rounds);        // most rounds / Newton iterations of one lane group
+    if (st_newton) atomicMax(&v.st->dbg_reason[3], st_newton);
 #endif
+#undef DOPF_TIC
+#undef DOPF_TOC
 
     // fixed-order block reduction of the per-timestep sums over the NG groups
     __syncthreads();

@@ -12,7 +12,7 @@ gmul = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 pp = synth.baseline_config(idx); A = pp.G + pp.S
 e = _capi.Engine(api, params=_capi.default_params(gamma=gmul/A, eps=0.0), **pp.engine_kwargs())
 def stats():
-    out = (C.c_uint64 * 9)(); api.lib.dopf_debug_stats(e._ctx, out); return np.array(list(out), dtype=np.float64)
+    out = (C.c_uint64 * 15)(); api.lib.dopf_debug_stats(e._ctx, out); return np.array(list(out), dtype=np.float64)
 s0 = stats()
 for it in range(n):
     e.iterate(1); s1 = stats(); d = s1 - s0; s0 = s1
