@@ -53,10 +53,11 @@ def cpu_baseline(pp, gamma, w_flow=10.0, budget_s=20.0):
     import __graft_entry__ as ge
     if not os.path.exists(ge.ORACLE_LIB):
         ge.build()
-    api = _capi.CApi(ge.ORACLE_LIB, "oracle_")
+    from oracle import binding as ob
+    api = ob.OracleApi(ge.ORACLE_LIB)
     cores = os.cpu_count() or 1
     e = _capi.Engine(api, params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0), mode=1, **pp.engine_kwargs())
-    e.set_threads(cores)
+    ob.set_threads(e, cores)
     t0 = time.perf_counter()
     e.iterate(1)
     t1 = time.perf_counter() - t0

@@ -3,9 +3,9 @@
 The product library is csrc/libdopf_hip.so (hand-written HIP for gfx950). There is NO CPU
 fallback: if the library is missing or HIP cannot start, loading raises.
 
-``CApi`` is generic over the symbol prefix because the CPU oracle (test infrastructure under
-oracle/) exports the same signatures prefixed ``oracle_``; only tests/, __graft_entry__.smoke()
-and bench.py's cpu_baseline leg ever point it at that library.
+``CApi`` is generic over the symbol prefix so that another library exporting the same
+signatures can be driven by the same Engine class (the test suite's checker does that from
+oracle/binding.py); nothing in this package knows about such a library.
 """
 from __future__ import annotations
 
@@ -54,6 +54,9 @@ F_OVERLAP_AGENTS = 2
 F_NO_WARM_START = 4
 F_NO_ROW_SKIP = 8
 F_NO_FUSE = 16
+F_COMM_HOST = 64
+F_DEBUG_ROOT_CAP = 128
+COMM_ID_BYTES = 128
 
 
 class DopfError(RuntimeError):
@@ -81,7 +84,7 @@ def _dp(arr: Optional[np.ndarray]):
 class CApi:
     """One loaded shared library exporting <prefix>create/iterate/... (include/dopf.h)."""
 
-    def __init__(self, path: str, prefix: str = "dopf_"):
+    def __init__(self, path: str, prefix: str = "dopf_", create_extra=()):
         if not os.path.exists(path):
             raise DopfError(
                 f"{path} not found: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
@@ -92,11 +95,10 @@ class CApi:
         p = prefix
         L = self.lib
         ctxp = C.c_void_p
-        self.has_mode = prefix != "dopf_"
+        self.has_mode = bool(create_extra)          # <prefix>create takes extra trailing arguments
         create = getattr(L, p + "create")
         create.restype = C.c_int
-        create.argtypes = [C.POINTER(ctxp), C.POINTER(DopfProblem), C.POINTER(DopfParams)] + (
-            [C.c_int32] if self.has_mode else [])
+        create.argtypes = [C.POINTER(ctxp), C.POINTER(DopfProblem), C.POINTER(DopfParams)] + list(create_extra)
         self._create = create
         self._sig("destroy", None, [ctxp])
         self._sig("last_error", C.c_char_p, [ctxp])
@@ -120,12 +122,20 @@ class CApi:
             self._sig("debug_stats", C.c_int, [ctxp, C.POINTER(C.c_uint64)])
             self._sig("version", C.c_char_p, [])
             self._sig("default_params", None, [C.POINTER(DopfParams)])
-        else:   # oracle-only entry points (tests)
-            self._sig("set_threads", None, [ctxp, C.c_int32])
             self._sig("get_agent_slacks", C.c_int, [ctxp, C.c_int32, c_double_p, c_double_p])
-            self._sig("calculate_ptdf", C.c_int, [C.c_int32, C.c_int32, c_int32_p, c_int32_p, c_double_p,
-                                                  C.c_int32, c_double_p])
-            self._sig("qp_solve", C.c_int, [C.c_int32, C.c_int32] + [c_double_p] * 8 + [c_int32_p])
+            self._sig("get_agent_penalty", C.c_int, [ctxp, C.c_int32, c_double_p, c_double_p])
+            self._sig("get_residual_vectors", C.c_int, [ctxp, c_double_p, c_double_p, c_double_p])
+            # consensus sum across GPUs inside the library (RCCL, loaded on first use)
+            self._sig("comm_unique_id", C.c_int, [C.c_void_p])
+            self._sig("comm_init", C.c_int, [ctxp, C.c_int32, C.c_int32, C.c_void_p])
+            self._sig("comm_info", C.c_int, [ctxp, c_int32_p, c_int32_p, c_int32_p])
+            self._sig("multi_create", C.c_int, [C.POINTER(ctxp), C.POINTER(DopfProblem), C.POINTER(DopfParams), C.c_int32, c_int32_p])
+            self._sig("multi_destroy", None, [ctxp])
+            self._sig("multi_last_error", C.c_char_p, [ctxp])
+            self._sig("multi_iterate", C.c_int, [ctxp, C.c_int32, c_int32_p, c_int32_p])
+            self._sig("multi_get_primal", C.c_int, [ctxp, c_double_p, c_double_p, c_double_p, c_double_p])
+            self._sig("multi_size", C.c_int32, [ctxp])
+            self._sig("multi_ctx", ctxp, [ctxp, C.c_int32])
 
     def _sig(self, name, restype, argtypes):
         f = getattr(self.lib, self.prefix + name)
@@ -245,8 +255,25 @@ class Engine:
         self._chk(self.api.debug_stats(self._ctx, out))
         return int(out[3]), int(out[4])
 
-    def set_threads(self, n: int):
-        self.api.set_threads(self._ctx, int(n))
+    # -- consensus sum across ranks inside the library (one process per GPU) ---------------------
+    def comm_unique_id(self) -> bytes:
+        """128 opaque bytes (ncclUniqueId): rank 0 creates them, every rank passes them to comm_init."""
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        rc = self.api.comm_unique_id(buf)
+        if rc != 0:
+            msg = self.api.last_error(None)
+            raise DopfError(f"dopf_comm_unique_id failed ({rc}): {msg.decode() if msg else ''}")
+        return buf.raw
+
+    def comm_init(self, world: int, rank: int, unique_id: bytes):
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        self._chk(self.api.comm_init(self._ctx, int(world), int(rank), buf))
+
+    def comm_info(self):
+        """(world, rank, collective captured in the hipGraph?)"""
+        w, r, g = C.c_int32(1), C.c_int32(0), C.c_int32(0)
+        self._chk(self.api.comm_info(self._ctx, C.byref(w), C.byref(r), C.byref(g)))
+        return w.value, r.value, bool(g.value)
 
     # -- getters -------------------------------------------------------------------------------
     def _duals(self, fn):
@@ -289,6 +316,29 @@ class Engine:
         self._chk(self.api.get_residuals(self._ctx, C.byref(a), C.byref(b), C.byref(c), C.byref(it)))
         return a.value, b.value, c.value, it.value
 
+    def get_residual_vectors(self):
+        """Convergence.{lambda_res, mue_res, rho_res}[end]: |dual change| per entry, (T), (L,T), (L,T)."""
+        lam = np.zeros(self.T)
+        mu = np.zeros(self.L * self.T)
+        rho = np.zeros(self.L * self.T)
+        self._chk(self.api.get_residual_vectors(self._ctx, _dp(lam), _dp(mu), _dp(rho)))
+        return lam, mu.reshape(self.T, self.L).T.copy(), rho.reshape(self.T, self.L).T.copy()
+
+    def get_agent_slacks(self, agent: int):
+        """ResultGenerator/ResultStorage.U, .K of the last solve, (L,T) each; agent: generators first."""
+        U = np.zeros(self.L * self.T)
+        K = np.zeros(self.L * self.T)
+        self._chk(self.api.get_agent_slacks(self._ctx, int(agent), _dp(U), _dp(K)))
+        return U.reshape(self.T, self.L).T.copy(), K.reshape(self.T, self.L).T.copy()
+
+    def get_agent_penalty(self, agent: int, delta=None):
+        """PenaltyTerm(energy_balance, upper_flow, lower_flow) of the agent's last solve, (T) each. `delta`: the
+        agent's injection change of that iteration; needed on a copper plate (the device keeps it only with lines)."""
+        pen = np.zeros(3 * self.T)
+        d = None if delta is None else _f64(delta, self.T)
+        self._chk(self.api.get_agent_penalty(self._ctx, int(agent), _dp(d), _dp(pen)))
+        return pen[:self.T].copy(), pen[self.T:2 * self.T].copy(), pen[2 * self.T:].copy()
+
     def get_nodal_price(self, which: int = 0):
         out = np.zeros(self.N * self.T)
         self._chk(self.api.get_nodal_price(self._ctx, int(which), _dp(out)))
@@ -305,3 +355,83 @@ class Engine:
         bufs = [am(P, self.G), am(D, self.S), am(C_, self.S), cm(avg_U, self.L), cm(avg_K, self.L),
                 None if lam is None else _f64(lam, self.T), cm(mu, self.L), cm(rho, self.L)]
         self._chk(self.api.set_state(self._ctx, *[_dp(b) for b in bufs], int(iteration)))
+
+
+class _ShardView(Engine):
+    """A shard's context inside a MultiEngine (owned by the dopf_multi object: never destroyed from here)."""
+
+    def __init__(self, api: CApi, ctx, N, L, T, G, S):     # noqa: super().__init__ deliberately not called
+        self.api, self._ctx = api, ctx
+        self.N, self.L, self.T, self.G, self.S = N, L, T, G, S
+
+    def close(self):
+        self._ctx = C.c_void_p()
+
+
+class MultiEngine:
+    """One process, n GPUs: dopf_multi_* (the library shards the agents, owns the RCCL communicator and one host
+    thread per device). Replicated state (duals, consensus, prices, residuals) is read from shard 0."""
+
+    def __init__(self, api: CApi, n_gpus: int, *, N, L, T, demand, ptdf, f_max, gen_mc, gen_pmax, gen_node,
+                 sto_mc, sto_pmax, sto_emax, sto_node, params: Optional[DopfParams] = None, devices=None):
+        self.api = api
+        self.N, self.L, self.T = int(N), int(L), int(T)
+        gen_mc = _f64(gen_mc)
+        sto_mc = _f64(sto_mc)
+        self.G, self.S = gen_mc.size, sto_mc.size
+        keep = dict(
+            demand=_f64(demand, self.N * self.T), ptdf=_f64(ptdf, self.L * self.N),
+            f_max=_f64(f_max, self.L), gen_mc=gen_mc, gen_pmax=_f64(gen_pmax, self.G),
+            gen_node=_i32(gen_node, self.G), sto_mc=sto_mc, sto_pmax=_f64(sto_pmax, self.S),
+            sto_emax=_f64(sto_emax, self.S), sto_node=_i32(sto_node, self.S))
+        prob = DopfProblem(N=self.N, L=self.L, T=self.T, G=self.G, S=self.S)
+        for k, v in keep.items():
+            setattr(prob, k, v.ctypes.data_as(c_int32_p if v.dtype == np.int32 else c_double_p))
+        self.params = params if params is not None else default_params()
+        dev = None if devices is None else _i32(devices, n_gpus)
+        self._m = C.c_void_p()
+        rc = api.multi_create(C.byref(self._m), C.byref(prob), C.byref(self.params), int(n_gpus),
+                              None if dev is None else dev.ctypes.data_as(c_int32_p))
+        if rc != 0:
+            msg = api.multi_last_error(None)
+            raise DopfError(f"dopf_multi_create failed ({rc}): {msg.decode() if msg else ''}")
+        self.n = int(api.multi_size(self._m))
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self.api.multi_last_error(self._m)
+            raise DopfError(f"dopf_multi_* failed ({rc}): {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "_m", None) is not None and self._m.value:
+            self.api.multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def iterate(self, n_iters: int):
+        done, conv = C.c_int32(0), C.c_int32(0)
+        self._chk(self.api.multi_iterate(self._m, int(n_iters), C.byref(done), C.byref(conv)))
+        return done.value, bool(conv.value)
+
+    def get_primal(self):
+        P = np.zeros(self.G * self.T)
+        D = np.zeros(self.S * self.T)
+        Cc = np.zeros(self.S * self.T)
+        E = np.zeros(self.S * self.T)
+        self._chk(self.api.multi_get_primal(self._m, _dp(P), _dp(D), _dp(Cc), _dp(E)))
+        return (P.reshape(self.G, self.T), D.reshape(self.S, self.T), Cc.reshape(self.S, self.T), E.reshape(self.S, self.T))
+
+    def shard(self, i: int = 0) -> Engine:
+        """Engine view of shard i's context (getters for the replicated state; do not iterate it directly)."""
+        ctx = C.c_void_p(self.api.multi_ctx(self._m, int(i)))
+        if not ctx.value:
+            raise IndexError(i)
+        def cut(total):              # the split dopf_multi_create makes (contiguous, remainder to the first shards)
+            base, rem = divmod(total, self.n)
+            return base + (1 if i < rem else 0)
+        return _ShardView(self.api, ctx, self.N, self.L, self.T, cut(self.G), cut(self.S))

@@ -16,7 +16,7 @@
 #include <string>
 #include <vector>
 
-#include "dopf_internal.h"
+#include "dopf_ctx.h"
 
 using namespace dopf;
 
@@ -28,24 +28,7 @@ thread_local char g_create_err[512];
 
 }  // namespace
 
-struct dopf_ctx {
-    DevView v{};
-    Launch lc{};
-    dopf_params q{};
-    int device = 0;
-    hipStream_t main = nullptr, side = nullptr;
-    bool own_main = false;
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
-    hipGraphExec_t graph1 = nullptr, graphU = nullptr;
-    bool graphs_valid = false;
-    std::vector<void *> allocs;
-    void *own_cons = nullptr;
-    std::vector<int> gen_perm, sto_perm;   // sorted position -> caller's index
-    Status host_st{};
-    char err[512] = {0};
-};
-
-namespace {
+namespace dopf {
 
 int fail(dopf_ctx *c, int code, const char *fmt, ...)
 {
@@ -56,12 +39,9 @@ int fail(dopf_ctx *c, int code, const char *fmt, ...)
     return code;
 }
 
-#define HIPCHK(c, call)                                                                          \
-    do {                                                                                         \
-        hipError_t e_ = (call);                                                                  \
-        if (e_ != hipSuccess)                                                                    \
-            return fail((c), DOPF_E_DEVICE, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
+}  // namespace dopf
+
+namespace {
 
 template <class Tp>
 int dev_alloc(dopf_ctx *c, Tp **out, size_t n, bool zero = true)
@@ -81,7 +61,8 @@ int dev_upload(dopf_ctx *c, const Tp **out, const std::vector<Tp> &h)
     Tp *p = nullptr;
     int rc = dev_alloc(c, &p, h.size(), false);
     if (rc) return rc;
-    if (!h.empty()) HIPCHK(c, hipMemcpyAsync(p, h.data(), h.size() * sizeof(Tp), hipMemcpyHostToDevice, c->main));
+    // blocking copy: the staging vector is usually a temporary that dies when this returns
+    if (!h.empty()) HIPCHK(c, hipMemcpy(p, h.data(), h.size() * sizeof(Tp), hipMemcpyHostToDevice));
     *out = p;
     return DOPF_OK;
 }
@@ -103,6 +84,10 @@ void make_items(const std::vector<int> &node_sorted, int N, int chunk, std::vect
     }
     node_item_beg[N] = (int)items.size();
 }
+
+}  // namespace
+
+namespace dopf {
 
 // single: the single-GPU dopf_iterate path (nothing reads cons between the reduce and the dual step)
 static bool slice_dual(const DevView &v, bool single)
@@ -149,18 +134,6 @@ void drop_graphs(dopf_ctx *c)
     c->graphs_valid = false;
 }
 
-int build_graph(dopf_ctx *c, int iters, hipGraphExec_t *out)
-{
-    hipGraph_t g = nullptr;
-    HIPCHK(c, hipStreamBeginCapture(c->main, hipStreamCaptureModeRelaxed));
-    for (int i = 0; i < iters; ++i) { enqueue_local(c, true); enqueue_apply(c, true); }
-    HIPCHK(c, hipStreamEndCapture(c->main, &g));
-    hipError_t e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
-    if (e != hipSuccess) return fail(c, DOPF_E_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e));
-    return DOPF_OK;
-}
-
 int read_status(dopf_ctx *c)
 {
     HIPCHK(c, hipMemcpyAsync(&c->host_st, c->v.st, sizeof(Status), hipMemcpyDeviceToHost, c->main));
@@ -168,11 +141,49 @@ int read_status(dopf_ctx *c)
     return DOPF_OK;
 }
 
-struct DeviceGuard {
-    int prev = -1;
-    explicit DeviceGuard(int dev) { hipGetDevice(&prev); if (dev != prev) hipSetDevice(dev); else prev = -1; }
-    ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
-};
+}  // namespace dopf
+
+namespace {
+
+// one iteration of the chain on the context's stream; a sharded context (dopf_comm_init) puts the all-reduce
+// of the consensus buffer between the local sums and the dual step
+int enqueue_iteration(dopf_ctx *c)
+{
+    const bool single = c->comm == nullptr;
+    enqueue_local(c, single);
+    if (!single) { const int rc = comm_enqueue_allreduce(c); if (rc) return rc; }
+    enqueue_apply(c, single);
+    return DOPF_OK;
+}
+
+int build_graph(dopf_ctx *c, int iters, hipGraphExec_t *out)
+{
+    hipGraph_t g = nullptr;
+    // (a sharded context captures the RCCL collective with the kernels; thread-local mode keeps the capture
+    // from tripping over what other host threads — other GPUs' drivers — do meanwhile)
+    HIPCHK(c, hipStreamBeginCapture(c->main, c->comm ? hipStreamCaptureModeThreadLocal : hipStreamCaptureModeRelaxed));
+    int rc = DOPF_OK;
+    for (int i = 0; i < iters && rc == DOPF_OK; ++i) rc = enqueue_iteration(c);
+    const hipError_t ec = hipStreamEndCapture(c->main, &g);
+    if (rc) { if (g) hipGraphDestroy(g); return rc; }
+    if (ec != hipSuccess) return fail(c, DOPF_E_DEVICE, "hipStreamEndCapture: %s", hipGetErrorString(ec));
+    hipError_t e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) return fail(c, DOPF_E_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    return DOPF_OK;
+}
+
+// a storage sub-problem that hit the root search's iteration cap leaves an unconverged row behind: report it
+int check_solver(dopf_ctx *c)
+{
+    if (c->host_st.solver_fail > c->solver_fail_seen) {
+        const unsigned long long n = c->host_st.solver_fail - c->solver_fail_seen;
+        c->solver_fail_seen = c->host_st.solver_fail;
+        return fail(c, DOPF_E_SOLVER, "%llu storage sub-problem(s) did not reach the root search's tolerance (%llu since creation)",
+                    n, (unsigned long long)c->host_st.solver_fail);
+    }
+    return DOPF_OK;
+}
 
 }  // namespace
 
@@ -198,6 +209,9 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         return fail(nullptr, DOPF_E_INVALID, "bad sizes N=%d L=%d T=%d G=%d S=%d", p->N, p->L, p->T, p->G, p->S);
     if (!(q->gamma > 0) || !(q->w_prox > 0) || !(q->w_flow > 0))
         return fail(nullptr, DOPF_E_INVALID, "gamma, w_prox, w_flow must be positive");
+    if (!p->demand || (p->L > 0 && (!p->ptdf || !p->f_max)) || (p->G > 0 && (!p->gen_mc || !p->gen_pmax || !p->gen_node)) ||
+        (p->S > 0 && (!p->sto_mc || !p->sto_pmax || !p->sto_emax || !p->sto_node)))
+        return fail(nullptr, DOPF_E_INVALID, "null array in dopf_problem (every array with a positive extent must be given)");
     for (int g = 0; g < p->G; ++g)
         if (p->gen_node[g] < 0 || p->gen_node[g] >= p->N) return fail(nullptr, DOPF_E_INVALID, "gen_node[%d] out of range", g);
     for (int s = 0; s < p->S; ++s)
@@ -238,6 +252,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     v.N = N; v.L = L; v.T = T; v.G = G; v.S = S; v.M2 = 2 * L;
     v.gamma = q->gamma; v.w_flow = q->w_flow; v.w_prox = q->w_prox; v.eps = q->eps; v.mask_thr = q->mask_thr;
     v.max_iters = q->max_iters;
+    v.rootCap = (q->flags & DOPF_F_DEBUG_ROOT_CAP) ? 2 : 80;
     const int A = q->n_agents_global > 0 ? q->n_agents_global : G + S;
     v.invA = A > 0 ? 1.0 / (double)A : 0.0;
     v.use_warm = (S > 0 && lc.stoNCH <= 3 && !(q->flags & DOPF_F_NO_WARM_START)) ? 1 : 0;
@@ -330,6 +345,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     TRY(dev_alloc(c, &v.lam_used, T)); TRY(dev_alloc(c, &v.mu_used, LT)); TRY(dev_alloc(c, &v.rho_used, LT));
     TRY(dev_alloc(c, &v.inj, NT)); TRY(dev_alloc(c, &v.s, T)); TRY(dev_alloc(c, &v.flow, LT));
     TRY(dev_alloc(c, &v.avgU, LT)); TRY(dev_alloc(c, &v.avgK, LT)); TRY(dev_alloc(c, &v.price, NT));
+    TRY(dev_alloc(c, &v.s_used, T)); TRY(dev_alloc(c, &v.flow_used, LT)); TRY(dev_alloc(c, &v.avgU_used, LT)); TRY(dev_alloc(c, &v.avgK_used, LT));
     if (L > 0) {
         TRY(dev_alloc(c, &v.tb_beta, NT * v.M2)); TRY(dev_alloc(c, &v.tb_psi, NT * v.M2));
         TRY(dev_alloc(c, &v.tb_slope, NT * (v.M2 + 1))); TRY(dev_alloc(c, &v.tb_psi0, NT));
@@ -369,6 +385,7 @@ void dopf_destroy(dopf_ctx *c)
     if (c->main) hipStreamSynchronize(c->main);
     if (c->side) hipStreamSynchronize(c->side);
     drop_graphs(c);
+    comm_release(c);
     for (void *p : c->allocs) hipFree(p);
     if (c->evFork) hipEventDestroy(c->evFork);
     if (c->evJoin) hipEventDestroy(c->evJoin);
@@ -382,13 +399,20 @@ int dopf_iterate(dopf_ctx *c, int32_t n_iters, int32_t *iters_done, int32_t *con
     if (!c || n_iters < 0) return fail(c, DOPF_E_INVALID, "bad argument");
     DeviceGuard guard(c->device);
     const int before = c->host_st.iters_total;
-    const bool eager = (c->q.flags & DOPF_F_NO_GRAPH) != 0;
+    bool eager = (c->q.flags & DOPF_F_NO_GRAPH) != 0;
     if (!eager && !c->graphs_valid) {
         int rc = build_graph(c, 1, &c->graph1);
-        if (rc) return rc;
-        rc = build_graph(c, kUnroll, &c->graphU);
-        if (rc) return rc;
-        c->graphs_valid = true;
+        if (rc == DOPF_OK) rc = build_graph(c, kUnroll, &c->graphU);
+        if (rc) {
+            if (!c->comm) return rc;
+            // the collective refused to be captured: launch the same chain eagerly from now on (no host sync either way)
+            drop_graphs(c);
+            (void)hipGetLastError();
+            c->q.flags |= DOPF_F_NO_GRAPH;
+            eager = true;
+        } else {
+            c->graphs_valid = true;
+        }
     }
     // Enqueue in slices and look at the device status word between slices, so that a converged (or capped)
     // run stops being fed no-op launches; one sync per kCheckEvery iterations costs nothing measurable.
@@ -397,7 +421,7 @@ int dopf_iterate(dopf_ctx *c, int32_t n_iters, int32_t *iters_done, int32_t *con
         int slice = std::min(left, kCheckEvery);
         left -= slice;
         if (eager) {
-            for (int i = 0; i < slice; ++i) { enqueue_local(c, true); enqueue_apply(c, true); }
+            for (int i = 0; i < slice; ++i) { const int rc = enqueue_iteration(c); if (rc) return rc; }
         } else {
             for (; slice >= kUnroll; slice -= kUnroll) HIPCHK(c, hipGraphLaunch(c->graphU, c->main));
             for (; slice > 0; --slice) HIPCHK(c, hipGraphLaunch(c->graph1, c->main));
@@ -410,7 +434,7 @@ int dopf_iterate(dopf_ctx *c, int32_t n_iters, int32_t *iters_done, int32_t *con
     if (n_iters == 0) { const int rc = read_status(c); if (rc) return rc; }
     if (iters_done) *iters_done = c->host_st.iters_total - before;
     if (converged) *converged = c->host_st.converged;
-    return DOPF_OK;
+    return check_solver(c);
 }
 
 int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
@@ -517,7 +541,7 @@ int dopf_sync(dopf_ctx *c, int32_t *iteration, int32_t *converged)
     if (rc) return rc;
     if (iteration) *iteration = c->host_st.iteration;
     if (converged) *converged = c->host_st.converged;
-    return DOPF_OK;
+    return check_solver(c);
 }
 
 static int copy_out(dopf_ctx *c, double *dst, const double *src, size_t n)
@@ -675,6 +699,95 @@ int dopf_set_state(dopf_ctx *c, const double *P, const double *D, const double *
     HIPCHK(c, hipStreamSynchronize(c->main));
     c->host_st = st;
     return DOPF_OK;
+}
+
+// Convergence.{lambda_res, mue_res, rho_res}[end] (src/structures/convergence.jl:5-12, src/optimization/convergence.jl:5-13):
+// |dual after the last update - dual the last solve used|, entry by entry
+int dopf_get_residual_vectors(dopf_ctx *c, double *lam_res, double *mu_res, double *rho_res)
+{
+    if (!c) return DOPF_E_INVALID;
+    const size_t T = c->v.T, LT = (size_t)c->v.L * c->v.T;
+    std::vector<double> a(std::max(T, LT)), b(std::max(T, LT));
+    auto diff = [&](double *out, const double *now, const double *used, size_t n) -> int {
+        if (!out || n == 0) return DOPF_OK;
+        DeviceGuard guard(c->device);
+        HIPCHK(c, hipMemcpyAsync(a.data(), now, n * sizeof(double), hipMemcpyDeviceToHost, c->main));
+        HIPCHK(c, hipMemcpyAsync(b.data(), used, n * sizeof(double), hipMemcpyDeviceToHost, c->main));
+        HIPCHK(c, hipStreamSynchronize(c->main));
+        for (size_t i = 0; i < n; ++i) out[i] = fabs(a[i] - b[i]);
+        return DOPF_OK;
+    };
+    int rc;
+    if ((rc = diff(lam_res, c->v.lam, c->v.lam_used, T))) return rc;
+    if ((rc = diff(mu_res, c->v.mu, c->v.mu_used, LT))) return rc;
+    return diff(rho_res, c->v.rho, c->v.rho_used, LT);
+}
+
+// ResultGenerator/ResultStorage.{U, K, penalty_term} of the last solve (src/structures/results.jl:1-17,
+// src/optimization/penalty_terms.jl:1-37): not stored per agent on the device — the slacks are eliminated in closed
+// form — but recomputed here from the agent's injection change and the consensus state that solve read.
+static int agent_result(dopf_ctx *c, int32_t agent, const double *delta_in, double *U, double *K, double *pen)
+{
+    const DevView &v = c->v;
+    const int T = v.T, L = v.L, N = v.N, G = v.G, S = v.S;
+    if (agent < 0 || agent >= G + S) return fail(c, DOPF_E_INVALID, "agent %d of %d", agent, G + S);
+    if (!delta_in && L == 0) {
+        if (pen) return fail(c, DOPF_E_UNSUPPORTED, "copper plate: the agent's injection change is not kept on the device (pass it in)");
+        return DOPF_OK;         // no lines: U and K are empty
+    }
+    DeviceGuard guard(c->device);
+    const bool is_gen = agent < G;
+    const std::vector<int> &perm = is_gen ? c->gen_perm : c->sto_perm;
+    const int want = is_gen ? agent : agent - G;
+    int row = -1;
+    for (size_t i = 0; i < perm.size(); ++i) if (perm[i] == want) { row = (int)i; break; }
+    if (row < 0) return fail(c, DOPF_E_INVALID, "agent not found");
+    HIPCHK(c, hipStreamSynchronize(c->main));
+    // node of the agent: the item lists are per node; read it from the node ranges
+    std::vector<int> beg(N + 1);
+    HIPCHK(c, hipMemcpy(beg.data(), is_gen ? v.node_gen_beg : v.node_sto_beg, sizeof(int) * (N + 1), hipMemcpyDeviceToHost));
+    int n = 0;
+    while (n + 1 < N && row >= beg[n + 1]) ++n;
+    std::vector<double> dl(T), s(T), f((size_t)L * T), aU((size_t)L * T), aK((size_t)L * T), h(L), F(L);
+    if (delta_in) memcpy(dl.data(), delta_in, sizeof(double) * T);
+    else HIPCHK(c, hipMemcpy(dl.data(), (is_gen ? v.dltG : v.dltS) + (size_t)row * T, sizeof(double) * T, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(s.data(), v.s_used, sizeof(double) * T, hipMemcpyDeviceToHost));
+    if (L > 0) {
+        const size_t LT = (size_t)L * T;
+        HIPCHK(c, hipMemcpy(f.data(), v.flow_used, sizeof(double) * LT, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(aU.data(), v.avgU_used, sizeof(double) * LT, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(aK.data(), v.avgK_used, sizeof(double) * LT, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(h.data(), v.ptdf + (size_t)L * n, sizeof(double) * L, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(F.data(), v.fmax, sizeof(double) * L, hipMemcpyDeviceToHost));
+    }
+    const double w2 = 2.0 * v.w_flow, g = v.gamma;
+    for (int t = 0; t < T; ++t) {
+        double up = 0.0, lo = 0.0;
+        for (int l = 0; l < L; ++l) {
+            const size_t i = l + (size_t)L * t;
+            const double fl = f[i] + h[l] * dl[t];
+            const double u = std::max(0.0, (g * aU[i] - w2 * (fl - F[l])) / (w2 + g));
+            const double k = std::max(0.0, (g * aK[i] + w2 * (fl + F[l])) / (w2 + g));
+            if (U) U[i] = u;
+            if (K) K[i] = k;
+            up += (fl + u - F[l]) * (fl + u - F[l]);                                           // penalty_terms.jl:10-20
+            lo += (k - fl - F[l]) * (k - fl - F[l]);                                           // :23-37
+        }
+        if (pen) { pen[t] = (s[t] + dl[t]) * (s[t] + dl[t]); pen[T + t] = up; pen[2 * T + t] = lo; }   // :3-7
+    }
+    return DOPF_OK;
+}
+
+int dopf_get_agent_slacks(dopf_ctx *c, int32_t agent, double *U, double *K)
+{
+    if (!c) return DOPF_E_INVALID;
+    return agent_result(c, agent, nullptr, U, K, nullptr);
+}
+
+int dopf_get_agent_penalty(dopf_ctx *c, int32_t agent, const double *delta, double *penalty)
+{
+    if (!c || !penalty) return DOPF_E_INVALID;
+    return agent_result(c, agent, delta, nullptr, nullptr, penalty);
 }
 
 // diagnostics: the breakpoint table of Psi_{n,t} as the last x-update saw it (L > 0 only)

@@ -1,0 +1,347 @@
+// dopf_comm.hip — the consensus sum across GPUs, inside the library.
+//
+// The reference has no parallelism; what shards is the agent loop of
+// optimize_all_subproblems! (src/optimization/subproblems.jl:1-17) and the only cross-agent data flow of an
+// iteration is the agent sum of Result(...) (src/structures/results.jl:72-106): ONE all-reduce(sum) of the
+// consensus buffer [N*T injections | L*T sum U | L*T sum K | cost] per iteration. Duals are then updated
+// redundantly on every rank, so they stay identical without a second collective.
+//
+// Two ways to get there, both ending in the same per-context chain
+//     k_agents ... k_reduce -> ncclAllReduce(consensus buffer, f64, sum, ctx stream) -> k_dual...
+// which dopf_iterate captures into its hipGraphs (RCCL collectives are capturable; if the capture is
+// refused the same chain is launched eagerly — still no host synchronisation per iteration):
+//   * one process per GPU (torch.distributed.run, MPI, Distributed.jl ...): every rank creates its own
+//     context from its shard of the agents and calls dopf_comm_init(ctx, world, rank, id) with the 128-byte
+//     id of dopf_comm_unique_id, carried from rank 0 to the others over any host channel;
+//   * one process, n GPUs (a Julia `ccall` host needs no launcher): dopf_multi_create shards the agents
+//     itself, creates one context per device, joins them with ncclCommInitAll and drives each from its own
+//     host thread in dopf_multi_iterate.
+// RCCL (librccl.so.1, the ROCm build of NCCL: rings / trees over xGMI) is loaded at run time, on the first
+// call that needs it: a single-GPU user of libdopf_hip never touches it.
+// DOPF_F_COMM_HOST replaces RCCL by a sum through host memory inside dopf_multi_iterate: a debugging
+// transport that lets several shards share ONE device (RCCL refuses two ranks on a device), which is how
+// the sharding logic of dopf_multi_* is tested on a one-GPU box.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "dopf_ctx.h"
+
+using namespace dopf;
+
+struct dopf_comm_state {
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0;
+    bool host_sum = false;      // DOPF_F_COMM_HOST: dopf_multi_iterate adds the buffers itself
+};
+
+namespace {
+
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    char err[256] = {0};
+};
+
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+void load_rccl()
+{
+    // A process that already carries RCCL (PyTorch ships its own copy) gets that very library; otherwise the
+    // system's is loaded privately (RTLD_LOCAL: a second copy loaded later by someone else must not see our symbols
+    // interposed over its own).
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (int k = 0; k < 2 && !g_rccl.lib; ++k) g_rccl.lib = dlopen(names[k], RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    for (const char *n : names) {
+        if (g_rccl.lib) break;
+        g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    }
+    if (!g_rccl.lib) { snprintf(g_rccl.err, sizeof g_rccl.err, "cannot load librccl.so.1: %s", dlerror()); return; }
+#define DOPF_SYM(field, name)                                                                   \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.lib, name));           \
+    if (!g_rccl.field) { snprintf(g_rccl.err, sizeof g_rccl.err, "librccl: no symbol %s", name); g_rccl.lib = nullptr; return; }
+    DOPF_SYM(GetUniqueId, "ncclGetUniqueId")
+    DOPF_SYM(CommInitRank, "ncclCommInitRank")
+    DOPF_SYM(CommInitAll, "ncclCommInitAll")
+    DOPF_SYM(CommDestroy, "ncclCommDestroy")
+    DOPF_SYM(AllReduce, "ncclAllReduce")
+    DOPF_SYM(GetErrorString, "ncclGetErrorString")
+#undef DOPF_SYM
+}
+
+const Rccl *rccl()
+{
+    std::call_once(g_rccl_once, load_rccl);
+    return g_rccl.lib ? &g_rccl : nullptr;
+}
+
+}  // namespace
+
+namespace dopf {
+
+int comm_enqueue_allreduce(dopf_ctx *c)
+{
+    dopf_comm_state *cs = c->comm;
+    if (!cs || cs->host_sum || cs->world == 1) return DOPF_OK;       // (host transport: dopf_multi_iterate adds)
+    const size_t n = (size_t)c->v.N * c->v.T + 2 * (size_t)c->v.L * c->v.T + 1;
+    const ncclResult_t r = g_rccl.AllReduce(c->v.cons, c->v.cons, n, ncclDouble, ncclSum, cs->comm, c->main);
+    if (r != ncclSuccess) return fail(c, DOPF_E_DEVICE, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
+    return DOPF_OK;
+}
+
+void comm_release(dopf_ctx *c)
+{
+    if (!c->comm) return;
+    if (c->comm->comm && g_rccl.lib) g_rccl.CommDestroy(c->comm->comm);
+    delete c->comm;
+    c->comm = nullptr;
+}
+
+}  // namespace dopf
+
+// ------------------------------------------------------------------------------------------------
+// one process, n GPUs
+// ------------------------------------------------------------------------------------------------
+struct dopf_multi {
+    int n = 0;
+    std::vector<dopf_ctx *> ctx;
+    std::vector<int> g0, g1, s0, s1;        // shard i owns generators [g0,g1), storages [s0,s1) of the caller's lists
+    int G = 0, S = 0, T = 0;
+    bool host_sum = false;
+    std::vector<double> hsum, hpart;
+    char err[512] = {0};
+};
+
+namespace {
+
+thread_local char g_multi_err[512];
+
+int mfail(dopf_multi *m, int code, const char *msg)
+{
+    snprintf(m ? m->err : g_multi_err, 512, "%s", msg);
+    return code;
+}
+
+// run f(i) for every shard, each on its own host thread (a context is driven by one thread at a time; the
+// RCCL collectives of the n ranks must be in flight together)
+template <class F>
+int for_each_shard(dopf_multi *m, F f)
+{
+    std::vector<int> rc(m->n, DOPF_OK);
+    if (m->n == 1) { rc[0] = f(0); }
+    else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < m->n; ++i) th.emplace_back([&, i] { rc[i] = f(i); });
+        for (auto &t : th) t.join();
+    }
+    for (int i = 0; i < m->n; ++i)
+        if (rc[i]) { snprintf(m->err, 512, "shard %d: %s", i, dopf_last_error(m->ctx[i])); return rc[i]; }
+    return DOPF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dopf_comm_unique_id(void *id128)
+{
+    if (!id128) return DOPF_E_INVALID;
+    const Rccl *r = rccl();
+    if (!r) return fail(nullptr, DOPF_E_DEVICE, "%s", g_rccl.err);
+    ncclUniqueId id;
+    const ncclResult_t e = r->GetUniqueId(&id);
+    if (e != ncclSuccess) return fail(nullptr, DOPF_E_DEVICE, "ncclGetUniqueId: %s", r->GetErrorString(e));
+    static_assert(sizeof id == DOPF_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id128, &id, sizeof id);
+    return DOPF_OK;
+}
+
+int dopf_comm_init(dopf_ctx *c, int32_t world, int32_t rank, const void *id128)
+{
+    if (!c || world < 1 || rank < 0 || rank >= world || !id128) return fail(c, DOPF_E_INVALID, "bad argument");
+    if (c->comm) return fail(c, DOPF_E_INVALID, "context already has a communicator");
+    const Rccl *r = rccl();
+    if (!r) return fail(c, DOPF_E_DEVICE, "%s", g_rccl.err);
+    DeviceGuard guard(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->main));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    dopf_comm_state *cs = new (std::nothrow) dopf_comm_state;
+    if (!cs) return fail(c, DOPF_E_NOMEM, "out of host memory");
+    cs->world = world; cs->rank = rank;
+    const ncclResult_t e = r->CommInitRank(&cs->comm, world, id, rank);
+    if (e != ncclSuccess) { delete cs; return fail(c, DOPF_E_DEVICE, "ncclCommInitRank: %s", r->GetErrorString(e)); }
+    c->comm = cs;
+    drop_graphs(c);          // the chain changes: the next dopf_iterate captures it anew
+    return DOPF_OK;
+}
+
+int dopf_comm_info(const dopf_ctx *c, int32_t *world, int32_t *rank, int32_t *in_graph)
+{
+    if (!c) return DOPF_E_INVALID;
+    if (world) *world = c->comm ? c->comm->world : 1;
+    if (rank) *rank = c->comm ? c->comm->rank : 0;
+    if (in_graph) *in_graph = (c->comm && c->graphs_valid) ? 1 : 0;
+    return DOPF_OK;
+}
+
+const char *dopf_multi_last_error(const dopf_multi *m) { return m ? m->err : g_multi_err; }
+
+void dopf_multi_destroy(dopf_multi *m)
+{
+    if (!m) return;
+    for (dopf_ctx *c : m->ctx) dopf_destroy(c);
+    delete m;
+}
+
+int dopf_multi_create(dopf_multi **out, const dopf_problem *p, const dopf_params *q, int32_t n_gpus, const int32_t *devices)
+{
+    if (!out || !p || !q || n_gpus < 1) return mfail(nullptr, DOPF_E_INVALID, "bad argument");
+    *out = nullptr;
+    const bool host_sum = (q->flags & DOPF_F_COMM_HOST) != 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return mfail(nullptr, DOPF_E_DEVICE, "no HIP device; libdopf_hip has no CPU fallback");
+    std::vector<int> dev(n_gpus);
+    for (int i = 0; i < n_gpus; ++i) {
+        dev[i] = devices ? devices[i] : (host_sum ? i % ndev : i);
+        if (dev[i] < 0 || dev[i] >= ndev) return mfail(nullptr, DOPF_E_INVALID, "device ordinal out of range (n_gpus exceeds the visible devices?)");
+        if (!host_sum)
+            for (int j = 0; j < i; ++j)
+                if (dev[j] == dev[i]) return mfail(nullptr, DOPF_E_INVALID, "RCCL needs one distinct device per shard (DOPF_F_COMM_HOST lifts this for tests)");
+    }
+    const Rccl *r = nullptr;
+    if (!host_sum && n_gpus > 1) {
+        r = rccl();
+        if (!r) return mfail(nullptr, DOPF_E_DEVICE, g_rccl.err);
+    }
+    dopf_multi *m = new (std::nothrow) dopf_multi;
+    if (!m) return mfail(nullptr, DOPF_E_NOMEM, "out of host memory");
+    m->n = n_gpus; m->G = p->G; m->S = p->S; m->T = p->T; m->host_sum = host_sum;
+    m->ctx.assign(n_gpus, nullptr);
+    m->g0.resize(n_gpus); m->g1.resize(n_gpus); m->s0.resize(n_gpus); m->s1.resize(n_gpus);
+    // contiguous slices of the caller's agent lists (the consensus sum does not care which agents a shard holds;
+    // each context sorts its own slice by node)
+    auto cut = [&](int total, int i, int &lo, int &hi) {
+        const int base = total / n_gpus, rem = total % n_gpus;
+        lo = i * base + std::min(i, rem);
+        hi = lo + base + (i < rem ? 1 : 0);
+    };
+    for (int i = 0; i < n_gpus; ++i) {
+        cut(p->G, i, m->g0[i], m->g1[i]);
+        cut(p->S, i, m->s0[i], m->s1[i]);
+        dopf_problem pi = *p;
+        pi.G = m->g1[i] - m->g0[i]; pi.S = m->s1[i] - m->s0[i];
+        pi.gen_mc = p->gen_mc ? p->gen_mc + m->g0[i] : nullptr; pi.gen_pmax = p->gen_pmax ? p->gen_pmax + m->g0[i] : nullptr;
+        pi.gen_node = p->gen_node ? p->gen_node + m->g0[i] : nullptr;
+        pi.sto_mc = p->sto_mc ? p->sto_mc + m->s0[i] : nullptr; pi.sto_pmax = p->sto_pmax ? p->sto_pmax + m->s0[i] : nullptr;
+        pi.sto_emax = p->sto_emax ? p->sto_emax + m->s0[i] : nullptr; pi.sto_node = p->sto_node ? p->sto_node + m->s0[i] : nullptr;
+        dopf_params qi = *q;
+        qi.device = dev[i];
+        qi.stream = nullptr;
+        qi.n_agents_global = q->n_agents_global > 0 ? q->n_agents_global : p->G + p->S;
+        const int rc = dopf_create(&m->ctx[i], &pi, &qi);
+        if (rc) {
+            snprintf(g_multi_err, 512, "shard %d: %s", i, dopf_last_error(nullptr));
+            dopf_multi_destroy(m);
+            return rc;
+        }
+    }
+    if (n_gpus > 1 || host_sum) {
+        std::vector<ncclComm_t> comms(n_gpus, nullptr);
+        if (!host_sum) {
+            const ncclResult_t e = r->CommInitAll(comms.data(), n_gpus, dev.data());
+            if (e != ncclSuccess) {
+                snprintf(g_multi_err, 512, "ncclCommInitAll: %s", r->GetErrorString(e));
+                dopf_multi_destroy(m);
+                return DOPF_E_DEVICE;
+            }
+        }
+        for (int i = 0; i < n_gpus; ++i) {
+            dopf_comm_state *cs = new dopf_comm_state;
+            cs->comm = comms[i]; cs->world = n_gpus; cs->rank = i; cs->host_sum = host_sum;
+            m->ctx[i]->comm = cs;
+        }
+        if (host_sum) {
+            const size_t n = (size_t)dopf_consensus_size(m->ctx[0]);
+            m->hsum.assign(n, 0.0); m->hpart.assign(n, 0.0);
+        }
+    }
+    *out = m;
+    return DOPF_OK;
+}
+
+int32_t dopf_multi_size(const dopf_multi *m) { return m ? m->n : 0; }
+
+dopf_ctx *dopf_multi_ctx(dopf_multi *m, int32_t i) { return (m && i >= 0 && i < m->n) ? m->ctx[i] : nullptr; }
+
+int dopf_multi_iterate(dopf_multi *m, int32_t n_iters, int32_t *iters_done, int32_t *converged)
+{
+    if (!m || n_iters < 0) return mfail(m, DOPF_E_INVALID, "bad argument");
+    std::vector<int32_t> done(m->n, 0), conv(m->n, 0);
+    int rc = DOPF_OK;
+    if (!m->host_sum) {
+        // every shard replays its own graph (kernels + its rank's part of the collective) from its own thread
+        rc = for_each_shard(m, [&](int i) { return dopf_iterate(m->ctx[i], n_iters, &done[i], &conv[i]); });
+    } else {
+        // debugging transport: local sums -> host -> sum in shard order -> every shard -> dual step
+        const size_t n = m->hsum.size();
+        int32_t it = 0, cv = 0;
+        rc = dopf_sync(m->ctx[0], &it, &cv);
+        const int32_t before = m->ctx[0]->host_st.iters_total;
+        for (int k = 0; k < n_iters && rc == DOPF_OK && !m->ctx[0]->host_st.halt; ++k) {
+            std::fill(m->hsum.begin(), m->hsum.end(), 0.0);
+            for (int i = 0; i < m->n && rc == DOPF_OK; ++i) {
+                dopf_ctx *c = m->ctx[i];
+                DeviceGuard guard(c->device);
+                rc = dopf_local_update(c);
+                if (rc) break;
+                if (hipMemcpyAsync(m->hpart.data(), c->v.cons, n * sizeof(double), hipMemcpyDeviceToHost, c->main) != hipSuccess ||
+                    hipStreamSynchronize(c->main) != hipSuccess) { rc = fail(c, DOPF_E_DEVICE, "consensus download failed"); break; }
+                for (size_t j = 0; j < n; ++j) m->hsum[j] += m->hpart[j];
+            }
+            for (int i = 0; i < m->n && rc == DOPF_OK; ++i) {
+                dopf_ctx *c = m->ctx[i];
+                DeviceGuard guard(c->device);
+                if (hipMemcpyAsync(c->v.cons, m->hsum.data(), n * sizeof(double), hipMemcpyHostToDevice, c->main) != hipSuccess) { rc = fail(c, DOPF_E_DEVICE, "consensus upload failed"); break; }
+                rc = dopf_apply_consensus(c);
+            }
+            if (rc == DOPF_OK) rc = dopf_sync(m->ctx[0], &it, &cv);
+        }
+        for (int i = 0; i < m->n && rc == DOPF_OK; ++i) rc = dopf_sync(m->ctx[i], &it, &conv[i]);
+        done[0] = m->ctx[0]->host_st.iters_total - before;
+        if (rc) snprintf(m->err, 512, "%s", dopf_last_error(m->ctx[0]));
+    }
+    if (rc) return rc;
+    // every shard computed the same stop test from the same sums
+    for (int i = 1; i < m->n; ++i)
+        if (conv[i] != conv[0] || m->ctx[i]->host_st.iteration != m->ctx[0]->host_st.iteration)
+            return mfail(m, DOPF_E_DEVICE, "shards disagree on the iteration state (consensus sum not identical on all ranks)");
+    if (iters_done) *iters_done = done[0];
+    if (converged) *converged = conv[0];
+    return DOPF_OK;
+}
+
+int dopf_multi_get_primal(dopf_multi *m, double *P, double *D, double *C, double *E)
+{
+    if (!m) return DOPF_E_INVALID;
+    const size_t T = (size_t)m->T;
+    for (int i = 0; i < m->n; ++i) {
+        const int rc = dopf_get_primal(m->ctx[i], P ? P + T * m->g0[i] : nullptr, D ? D + T * m->s0[i] : nullptr,
+                                       C ? C + T * m->s0[i] : nullptr, E ? E + T * m->s0[i] : nullptr);
+        if (rc) { snprintf(m->err, 512, "shard %d: %s", i, dopf_last_error(m->ctx[i])); return rc; }
+    }
+    return DOPF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+// dopf_ctx.h — the context behind the C ABI, shared by dopf_api.hip and dopf_comm.hip (internal).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "dopf_internal.h"
+
+struct dopf_comm_state;     // dopf_comm.hip: RCCL communicator of a sharded context
+
+struct dopf_ctx {
+    dopf::DevView v{};
+    dopf::Launch lc{};
+    dopf_params q{};
+    int device = 0;
+    hipStream_t main = nullptr, side = nullptr;
+    bool own_main = false;
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipGraphExec_t graph1 = nullptr, graphU = nullptr;
+    bool graphs_valid = false;
+    std::vector<void *> allocs;
+    void *own_cons = nullptr;
+    std::vector<int> gen_perm, sto_perm;   // sorted position -> caller's index
+    dopf::Status host_st{};
+    unsigned long long solver_fail_seen = 0;   // failures already reported through DOPF_E_SOLVER
+    dopf_comm_state *comm = nullptr;       // non-null: dopf_iterate runs local_update -> all-reduce -> apply_consensus
+    char err[512] = {0};
+};
+
+namespace dopf {
+
+int fail(dopf_ctx *c, int code, const char *fmt, ...);
+void enqueue_local(dopf_ctx *c, bool single);
+void enqueue_apply(dopf_ctx *c, bool single);
+void drop_graphs(dopf_ctx *c);
+int read_status(dopf_ctx *c);
+// dopf_comm.hip
+int comm_enqueue_allreduce(dopf_ctx *c);      // sum of the consensus buffer over the ranks, on the context's stream
+void comm_release(dopf_ctx *c);
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { hipGetDevice(&prev); if (dev != prev) hipSetDevice(dev); else prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+};
+
+#define HIPCHK(c, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return dopf::fail((c), DOPF_E_DEVICE, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+}  // namespace dopf

@@ -54,6 +54,7 @@ struct DevView {
     int fuseAgents;                 // copper plate, even T: generators + storages in one launch (k_agents, 256-thread blocks)
     int use_warm;                   // storage warm-start kernel runs first; the scan kernel serves its failures
     int max_iters;
+    int rootCap;                    // iteration cap of the scan kernel's root search (80; 2 with DOPF_F_DEBUG_ROOT_CAP)
     double gamma, w_flow, w_prox, eps, mask_thr, invA;
     // problem (read-only)
     const double *demand, *ptdf, *fmax;
@@ -70,6 +71,7 @@ struct DevView {
     // duals and consensus state
     double *lam, *mu, *rho, *lam_used, *mu_used, *rho_used;
     double *inj, *s, *flow, *avgU, *avgK, *price;
+    double *s_used, *flow_used, *avgU_used, *avgK_used;   // what the last x-update read (diagnostic getters: per-agent U, K, penalty terms)
     // tables
     double *tb_beta, *tb_psi, *tb_slope, *tb_psi0;
     int *tb_m;

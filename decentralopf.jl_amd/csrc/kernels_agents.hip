@@ -674,7 +674,7 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
             if (active && mode == 1) {
                 const double res = level_at(vv) - target;
                 if (res < 0.0) lo = nu; else hi = nu;
-                bool conv = fabs(res) <= 1e-12 * (1.0 + ag.em) || rit >= 80;
+                bool conv = fabs(res) <= 1e-12 * (1.0 + ag.em) || rit >= v.rootCap;
                 double trial = nu;
                 if (!conv) {
                     const double sl = slope_at(vv);
@@ -694,7 +694,7 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
                     if (!(trial > lo && trial < hi)) conv = true;   // bracket is two adjacent doubles
                 }
                 if (conv) {
-                    if (rit >= 80 && fabs(res) > 1e-7 * (1.0 + ag.em) && li == 0) ++fails;
+                    if (rit >= v.rootCap && fabs(res) > 1e-7 * (1.0 + ag.em) && li == 0) ++fails;
 #pragma unroll
                     for (int c = 0; c < NCH; ++c)
                         if (tbase + c == vv) nuf[c] = nu;

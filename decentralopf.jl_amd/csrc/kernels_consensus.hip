@@ -464,6 +464,7 @@ __device__ __forceinline__ void dual_body(const DevView &v, size_t i, double &rl
 #pragma unroll
             for (int u = 0; u < 8; ++u) sum += x[u];
         }
+        if (UPDATE) v.s_used[t] = v.s[t];
         v.s[t] = sum;
         if (UPDATE) {
             const double lo = v.lam[t], ln = lo + v.gamma * sum;          // update_duals.jl:8-13
@@ -486,6 +487,7 @@ __device__ __forceinline__ void dual_body(const DevView &v, size_t i, double &rl
 #pragma unroll
             for (int u = 0; u < 8; ++u) f += h[u] * q[u];
         }
+        if (UPDATE) { v.flow_used[i] = v.flow[i]; v.avgU_used[i] = v.avgU[i]; v.avgK_used[i] = v.avgK[i]; }
         v.flow[i] = f;                                                    // results.jl:114
         if (UPDATE) {
             const double aU = v.invA * cU[i], aK = v.invA * cK[i];       // results.jl:108-112
@@ -600,6 +602,7 @@ __global__ __launch_bounds__(256) void k_dual_t(DevView v)
     const double sum = block_sum256(part, red);                              // (barriers inside: q[] is complete)
     double rl = 0.0, rm = 0.0, rr = 0.0;
     if (tid == 0) {
+        if (UPDATE) v.s_used[t] = v.s[t];
         v.s[t] = sum;
         if (UPDATE) {
             const double lo = v.lam[t], ln = lo + v.gamma * sum;             // update_duals.jl:8-13
@@ -618,6 +621,7 @@ __global__ __launch_bounds__(256) void k_dual_t(DevView v)
             for (int u = 0; u < 8; ++u) f += h[u] * (n0 + u < N ? q[n0 + u] : 0.0);
         }
         const size_t i = l + (size_t)L * t;
+        if (UPDATE) { v.flow_used[i] = v.flow[i]; v.avgU_used[i] = v.avgU[i]; v.avgK_used[i] = v.avgK[i]; }
         v.flow[i] = f;                                                       // results.jl:114
         if (UPDATE) {
             const double aU = v.invA * cU[i], aK = v.invA * cK[i];          // results.jl:108-112

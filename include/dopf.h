@@ -103,6 +103,10 @@ typedef struct dopf_params {
 #define DOPF_F_NO_WARM_START 4  /* storages: always the cold price-threshold scan (no warm-start kernel) */
 #define DOPF_F_NO_FUSE      16  /* copper plate: generator and storage x-updates as separate launches instead
                                    of the single k_agents launch                                           */
+#define DOPF_F_COMM_HOST    64  /* dopf_multi_*: sum the consensus buffers through host memory instead of RCCL — a
+                                   debugging transport that lets several shards share one device (tests)      */
+#define DOPF_F_DEBUG_ROOT_CAP 128 /* tests: the scan kernel's root search gives up after 2 iterations instead of
+                                   80, so that the DOPF_E_SOLVER path can be exercised                        */
 
 /* Fill q with the reference's defaults (values above). */
 void dopf_default_params(dopf_params *q);
@@ -115,7 +119,13 @@ const char *dopf_last_error(const dopf_ctx *ctx);
 /* Run up to n_iters ADMM iterations back to back on the device, one host sync at the end.
  * Stops exactly like check_convergence!: no test at iteration 1; on the converging step the
  * iteration counter is NOT bumped and later iterations in the same call are no-ops.
- * iters_done = iterations actually computed in this call; converged = Convergence.all. */
+ * iters_done = iterations actually computed in this call; converged = Convergence.all.
+ * Returns DOPF_E_SOLVER (outputs are still set, the state is still advanced) when a storage
+ * sub-problem's root search hit its iteration cap since the last report: that row is not the
+ * minimiser of its QP (the reference would surface a Gurobi failure from value.() at this point,
+ * src/optimization/subproblems.jl:189-206). dopf_sync reports the same.
+ * On a context joined to a communicator (dopf_comm_init / dopf_multi_create) every iteration
+ * includes the all-reduce of the consensus buffer; all ranks must call with the same n_iters. */
 int dopf_iterate(dopf_ctx *ctx, int32_t n_iters, int32_t *iters_done, int32_t *converged);
 
 /* Sharded form of one iteration (one process per GPU):
@@ -142,6 +152,19 @@ int dopf_get_consensus(dopf_ctx *ctx, double *injection /*N*T*/, double *avg_U, 
                        double *line_util /*L*T each*/, double *total_cost /*1*/);
 int dopf_get_residuals(dopf_ctx *ctx, double *lam_res, double *mu_res, double *rho_res,
                        int32_t *iteration);
+/* Convergence.{lambda_res, mue_res, rho_res}[end] as vectors (src/structures/convergence.jl:5-12):
+ * |dual after the last update - dual the last solve used| per entry; any pointer may be NULL. */
+int dopf_get_residual_vectors(dopf_ctx *ctx, double *lam_res /*T*/, double *mu_res /*L*T*/, double *rho_res /*L*T*/);
+/* ResultGenerator/ResultStorage.{U, K} of the last solve (src/structures/results.jl:1-17), L x T each,
+ * [l + L*t]; agent = caller's index, generators 0..G-1 then storages G..G+S-1 (of this context's shard).
+ * The device eliminates the slacks in closed form; they are recomputed here from the agent's injection
+ * change and the consensus state that solve read. */
+int dopf_get_agent_slacks(dopf_ctx *ctx, int32_t agent, double *U, double *K);
+/* PenaltyTerm of the agent (src/structures/penalty_terms.jl:1-5, src/optimization/penalty_terms.jl:3-37):
+ * penalty[0..T) energy_balance, [T..2T) upper_flow, [2T..3T) lower_flow — the diagnostics print_results shows
+ * with print_penalty=true. delta = the agent's injection change of the last iteration (T values), or NULL to
+ * use the device's copy, which exists only when L > 0 (DOPF_E_UNSUPPORTED otherwise). */
+int dopf_get_agent_penalty(dopf_ctx *ctx, int32_t agent, const double *delta, double *penalty /*3*T*/);
 /* which = 0: duals used by the last solve (what the reference's driver script evaluates),
  * which = 1: duals after the last update. out is N x T, [n + N*t]. */
 int dopf_get_nodal_price(dopf_ctx *ctx, int32_t which, double *out);
@@ -168,10 +191,44 @@ typedef struct dopf_timing {
 int dopf_iterate_timed(dopf_ctx *ctx, int32_t n_iters, dopf_timing *out);
 
 int64_t dopf_solver_failures(dopf_ctx *ctx);
-/* Diagnostics, 9 counters: [0..2] scan-kernel statistics (only in -DDOPF_STATS builds), [3] storages the
- * warm-start kernel solved in the LAST iteration, [4] storages it left to the scan kernel, [5..8] reasons
- * (DOPF_STATS builds). */
-int dopf_debug_stats(dopf_ctx *ctx, uint64_t *out9);
+
+/* ---- consensus sum across GPUs inside the library (RCCL over xGMI, loaded at run time) -------------
+ * Replaces nothing in the reference (it has no parallelism); what is distributed is the agent loop of
+ * optimize_all_subproblems! (src/optimization/subproblems.jl:1-17) and the agent sums of Result(...)
+ * (src/structures/results.jl:72-106), summed over ranks by ONE all-reduce per iteration.
+ *
+ * One process per GPU: every rank creates its context from its shard (dopf_problem.G/S = local agents,
+ * dopf_params.n_agents_global = all agents), rank 0 calls dopf_comm_unique_id and ships the 128 bytes to
+ * the other ranks over any host channel (MPI, torch.distributed, a file), every rank calls dopf_comm_init.
+ * From then on dopf_iterate runs local_update -> all-reduce -> apply_consensus per iteration, captured in
+ * its hipGraphs (launched eagerly if RCCL refuses the capture); no host round trip per iteration. */
+#define DOPF_COMM_ID_BYTES 128
+int dopf_comm_unique_id(void *id128);
+int dopf_comm_init(dopf_ctx *ctx, int32_t world, int32_t rank, const void *id128);
+/* world / rank of the context's communicator (1 / 0 without one); in_graph = 1 once dopf_iterate has
+ * captured the collective into its graphs, 0 while it launches eagerly. Any pointer may be NULL. */
+int dopf_comm_info(const dopf_ctx *ctx, int32_t *world, int32_t *rank, int32_t *in_graph);
+
+/* One process, n GPUs — what a Julia `ccall` host uses (no launcher): p holds ALL agents; the library
+ * cuts the agent lists into n contiguous shards, creates one context per device (devices[i], or 0..n-1
+ * when NULL), joins them with ncclCommInitAll and drives each from its own host thread.
+ * Replaces ADMM(...) + run!(admm) exactly like dopf_create + dopf_iterate do on one GPU. */
+typedef struct dopf_multi dopf_multi;
+int  dopf_multi_create(dopf_multi **out, const dopf_problem *p, const dopf_params *q, int32_t n_gpus,
+                       const int32_t *devices);
+void dopf_multi_destroy(dopf_multi *m);
+const char *dopf_multi_last_error(const dopf_multi *m);   /* m == NULL: last dopf_multi_create error */
+int  dopf_multi_iterate(dopf_multi *m, int32_t n_iters, int32_t *iters_done, int32_t *converged);
+/* Primal rows of all shards in the caller's agent order (layout of dopf_get_primal). */
+int  dopf_multi_get_primal(dopf_multi *m, double *P, double *D, double *C, double *E);
+int32_t dopf_multi_size(const dopf_multi *m);
+/* Shard i's context: duals, consensus state, residuals and prices are replicated, read them from
+ * shard 0 with the dopf_get_* calls above. */
+dopf_ctx *dopf_multi_ctx(dopf_multi *m, int32_t i);
+/* Diagnostics, 15 counters: [0..2] scan-kernel statistics (only in -DDOPF_STATS builds), [3] storages the
+ * active-set kernel certified in the LAST iteration, [4] storages it left to the scan kernel, [5..8] contact-set
+ * rounds / Newton iterations (sum, max per lane group), [9..14] cycles per section (DOPF_STATS builds). */
+int dopf_debug_stats(dopf_ctx *ctx, uint64_t *out15);
 /* Diagnostics (L > 0): the breakpoint table of node n, timestep t that the last x-update used:
  * beta, psi: 2L doubles (first *m valid, ascending), slope: 2L+1, psi0 = Psi(0). */
 int dopf_debug_table(dopf_ctx *ctx, int32_t n, int32_t t, double *beta, double *psi, double *slope,

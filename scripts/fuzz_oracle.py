@@ -8,7 +8,8 @@ pkg = dopf_pkg.load()
 from decentralopf_jl_amd import _capi, synth
 from helpers import make_engine, state_of, max_diff
 import __graft_entry__ as ge
-ora = _capi.CApi(ge.ORACLE_LIB, "oracle_")
+from oracle.binding import OracleApi
+ora = OracleApi(ge.ORACLE_LIB)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 worst_all, bad, fails = 0.0, 0, 0

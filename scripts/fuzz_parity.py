@@ -8,7 +8,8 @@ from decentralopf_jl_amd import _capi, synth
 from helpers import make_engine, state_of, max_diff
 import __graft_entry__ as ge
 hip = _capi.CApi(os.environ["DOPF_LIB"], "dopf_") if os.environ.get("DOPF_LIB") else _capi.hip_api()
-ora = _capi.CApi(ge.ORACLE_LIB, "oracle_")
+from oracle.binding import OracleApi
+ora = OracleApi(ge.ORACLE_LIB)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 MODE = int(os.environ.get("ORACLE_MODE", "1"))      # 0: the literal mode (interior point, keep the cases small), 1: exact
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)

@@ -1,13 +1,16 @@
 #!/bin/bash
 # PMC counters for the storage / generator kernels (separate pass from any tracing, as the pool requires)
+#   prof_pmc.sh <workload> [extra bench.py flags, e.g. "--flags 16" = separate generator / storage launches]
 set -e
 cd /tmp && export TMPDIR=/tmp
 W=${1:-config4}
+X=${2:-}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$W
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/p1 -- python3 bench.py --workload $W --no-cpu-baseline --steps 20 --warmup 4 --timed-iters 2 > $OUT/p1.log 2>&1
-rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/p2 -- python3 bench.py --workload $W --no-cpu-baseline --steps 20 --warmup 4 --timed-iters 2 > $OUT/p2.log 2>&1
+ARGS="bench.py --workload $W --no-cpu-baseline --no-also --steps 40 --warmup 60 --timed-iters 2 $X"
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/p1 -- python3 $ARGS > $OUT/p1.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/p2 -- python3 $ARGS > $OUT/p2.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 for p in ("p1","p2"):
@@ -18,6 +21,6 @@ for p in ("p1","p2"):
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
             cnt[(k, r["Counter_Name"])] += 1
         for k, d in agg.items():
-            if "k_sto" in k or "k_gen" in k or "k_reduce" in k:
+            if "k_sto" in k or "k_gen" in k or "k_reduce" in k or "k_agents" in k or "k_dual" in k:
                 print(k, {c: round(v / cnt[(k, c)]) for c, v in d.items()})
 PY

@@ -23,9 +23,10 @@ if RAND:
     pp.sto_mc = rng.uniform(0.5, 3.5, pp.S); pp.sto_pmax = rng.uniform(5, 20, pp.S); pp.sto_emax = pp.sto_pmax * rng.uniform(0.7, 4.0, pp.S)
 A = pp.G + pp.S
 gam, w = GMUL / A, 1.0
-api = _capi.CApi(ge.ORACLE_LIB, "oracle_")
+from oracle.binding import OracleApi, set_threads
+api = OracleApi(ge.ORACLE_LIB)
 eng = _capi.Engine(api, params=_capi.default_params(gamma=gam, eps=0.0), mode=1, **pp.engine_kwargs())
-eng.set_threads(8)
+set_threads(eng, 8)
 T, S = pp.T, pp.S
 a0 = w + gam
 idet0 = 1.0 / (a0 * a0 - gam * gam)

@@ -32,7 +32,8 @@ def build_oracle():
 @pytest.fixture(scope="session")
 def oracle_api():
     """The CPU oracle — the checker. Never part of the product path."""
-    return _capi.CApi(build_oracle(), "oracle_")
+    from oracle.binding import OracleApi
+    return OracleApi(build_oracle())
 
 
 @pytest.fixture(scope="session")

@@ -30,7 +30,8 @@ def _worker(rank, world, port, case, iters, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pp = synth.synthetic_case(**case)
-    api = _capi.CApi(ORACLE_LIB, "oracle_")
+    from oracle.binding import OracleApi
+    api = OracleApi(ORACLE_LIB)
     holder = {}
 
     def all_reduce():
