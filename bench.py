@@ -8,16 +8,23 @@ A "step" is one ADMM iteration (all agent x-updates + consensus + dual update + 
 synthetic N-agent x T-timestep grid that is resident in HBM before the timed region starts.
 Prints ONE JSON line on rank 0:
   metric/value   agent-subproblem-updates per second, whole job (= agents x iterations / s)
-  roofline       generator x-update kernel: algorithmic bytes per launch / its HIP-event duration
+  roofline       the x-update launch: algorithmic bytes per launch / its HIP-event duration, over the timed region
+                 (`frac`) and in steady state; `traffic` = HBM bytes per launch from the committed PMC passes
   cpu_baseline   the oracle's exact mode (a "port", oracle/dopf_oracle.c) on the host cores, bounded sample
 Workloads (BASELINE.json `configs`): config1 = 1k gens + 100 storages x 24; config2 = 50k agents x 96
 (default: the largest single-GPU configuration); config4 = 1M agents x 24; config3 = 118-node/186-line
-synthetic network, 100k agents x 168. With --gpus N every rank holds one such grid (weak scaling) and
-the per-iteration consensus sum is one RCCL all-reduce.
+synthetic network, 100k agents x 168.
+
+--gpus N > 1 without a torch.distributed.run environment: this process starts the N ranks itself (children,
+one per GPU, before anything here touches the GPU) and relays rank 0's line. Every rank holds one full grid
+(weak scaling); the per-iteration consensus sum is ONE RCCL all-reduce issued by the library itself
+(dopf_comm_init: captured with the kernels in the iteration's hipGraph), `--comm torch` keeps the older path
+where torch.distributed issues it between two library calls.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,8 +40,20 @@ WORKLOADS = {
     # (with --gpus 8 every rank owns such a share: the configuration itself)
     "config3-share": (3, "one GPU's share (12.5k of 100k agents) of the synthetic 118-node/186-line network, 168 timesteps "
                          "(BASELINE configs[3] is an 8-GPU run; graph is synthetic)"),
+    # HBM stress beyond the 256 MiB Infinity Cache: P alone is 384 MB
+    "config4x2": (5, "synthetic 1M agents, 48 timesteps, copper plate: config4 with twice the horizon, so that the generator "
+                     "array (384 MB) no longer fits the 256 MiB Infinity Cache"),
 }
 SHARE = {"config3-share": 0.125}
+PEAK_GBPS = 8000.0        # HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
+
+
+def make_problem(synth, wl, scale=1.0):
+    idx = WORKLOADS[wl][0]
+    if idx == 5:
+        a = int(1000000 * scale)
+        return synth.synthetic_case(a - a // 11, a // 11, 48)
+    return synth.baseline_config(idx, scale=scale * SHARE.get(wl, 1.0))
 
 
 def algorithmic_bytes(G, S, T, N, L):
@@ -46,33 +65,94 @@ def algorithmic_bytes(G, S, T, N, L):
     return gen, sto, shared
 
 
-def cpu_baseline(pp, gamma, w_flow=10.0, budget_s=20.0):
-    """Oracle (exact mode) on the host cores: a bounded number of iterations of the SAME problem."""
-    import numpy as np  # noqa: F401
+def cpu_baseline(pp, gamma, w_flow, synth, budget_s=14.0):
+    """Oracle (exact mode) on the host cores: all cores on a bounded number of iterations of the SAME problem, and one
+    core on a 1/25 cut of it (same generator, horizon and penalty; a full iteration on one core takes minutes)."""
     from decentralopf_jl_amd import _capi
+    from oracle import binding as ob
     import __graft_entry__ as ge
     if not os.path.exists(ge.ORACLE_LIB):
         ge.build()
-    from oracle import binding as ob
     api = ob.OracleApi(ge.ORACLE_LIB)
-    cores = os.cpu_count() or 1
-    e = _capi.Engine(api, params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0), mode=1, **pp.engine_kwargs())
-    ob.set_threads(e, cores)
-    t0 = time.perf_counter()
-    e.iterate(1)
-    t1 = time.perf_counter() - t0
-    n = 1
-    extra = int(max(0, min(50, (budget_s - t1) // max(t1, 1e-6))))
-    if extra > 0:
+    # the process's CPU share, not the machine's thread count (a one-GPU lease of the pool is 16 CPUs of a 256-thread host)
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+
+    def run(problem, threads, budget):
+        e = _capi.Engine(api, params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0), mode=ob.MODE_EXACT,
+                         **problem.engine_kwargs())
+        ob.set_threads(e, threads)
         t0 = time.perf_counter()
-        e.iterate(extra)
-        t1 += time.perf_counter() - t0
-        n += extra
+        e.iterate(1)
+        t1 = time.perf_counter() - t0
+        n = 1
+        extra = int(max(0, min(50, (budget - t1) // max(t1, 1e-6))))
+        if extra > 0:
+            t0 = time.perf_counter()
+            e.iterate(extra)
+            t1 += time.perf_counter() - t0
+            n += extra
+        e.close()
+        return n, t1
     A = pp.G + pp.S
-    return {"value": A * n / t1, "unit": "agent-updates/s", "cores": cores, "kind": "port",
-            "sample": f"{n} ADMM iteration(s) of the same workload from the zero state, oracle exact mode, "
-                      f"OpenMP over agents ({t1:.1f} s)",
-            "iters_per_sec": n / t1}
+    n, t1 = run(pp, cores, budget_s)
+    out = {"value": A * n / t1, "unit": "agent-updates/s", "cores": cores, "kind": "port",
+           "sample": f"{n} ADMM iteration(s) of the same workload from the zero state, oracle exact mode, "
+                     f"OpenMP over agents ({t1:.1f} s)",
+           "iters_per_sec": n / t1,
+           "note": "a reported baseline, not the target: the reference's own JuMP/Gurobi path cannot be timed (no Julia, no licence); "
+                   "the GPU/CPU ratio says nothing about kernel quality, roofline.frac does"}
+    if pp.meta.get("n_gen"):
+        cut = synth.synthetic_case(max(1, pp.G // 25), max(1, pp.S // 25), pp.T, N=pp.N, L=pp.L, seed=pp.meta.get("seed", synth.SEED))
+        n1, t11 = run(cut, 1, budget_s / 2)
+        out["one_core"] = {"value": (cut.G + cut.S) * n1 / t11, "unit": "agent-updates/s", "cores": 1,
+                           "sample": f"{n1} iteration(s) of a 1/25 cut of the workload ({cut.G}+{cut.S} agents, same horizon and "
+                                     f"penalty), one thread ({t11:.1f} s)"}
+    return out
+
+
+def self_launch(args, argv):
+    """--gpus N without a launcher: start the N ranks as children (this process never touches the GPU), relay
+    rank 0's JSON line. A run that hangs is killed at the deadline and retried on the next communication mode."""
+    import socket
+    modes = [args.comm] if args.comm != "auto" else ["lib", "lib-eager", "torch"]
+    last = ""
+    rest, skip = [], False
+    for a in argv:                      # the children get the mode of the attempt: drop --comm X / --comm=X
+        if skip:
+            skip = False
+        elif a == "--comm":
+            skip = True
+        elif not a.startswith("--comm="):
+            rest.append(a)
+    for mode in modes:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + \
+              rest + [f"--comm={mode}"]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=sys.stderr, env=env, start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=args.launch_timeout)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, 9)          # exactly the process group started above
+            except ProcessLookupError:
+                pass
+            p.wait()
+            last = f"mode {mode}: no result within {args.launch_timeout} s"
+            print(f"bench.py: {last}; trying the next mode", file=sys.stderr)
+            continue
+        lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
+        if p.returncode == 0 and lines:
+            sys.stdout.write(lines[-1] + "\n")
+            sys.stdout.flush()
+            return 0
+        last = f"mode {mode}: exit code {p.returncode}"
+        print(f"bench.py: {last}; trying the next mode", file=sys.stderr)
+    print(f"bench.py: multi-GPU run failed ({last})", file=sys.stderr)
+    return 1
 
 
 def main():
@@ -89,10 +169,24 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="fork the storage kernel onto a side stream")
     ap.add_argument("--flags", type=int, default=0, help="DOPF_F_* bits (include/dopf.h), e.g. 16 = separate generator/storage launches")
     ap.add_argument("--no-also", action="store_true", help="skip the short side runs of the other single-GPU workloads")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl (= RCCL) is the product path, gloo only to "
-                                                      "rehearse the multi-rank logic on a box with fewer GPUs than ranks")
+    ap.add_argument("--comm", default="auto", choices=["auto", "lib", "lib-eager", "torch"],
+                    help="N > 1: who issues the all-reduce. lib = the library's own RCCL communicator, captured in the hipGraph "
+                         "(lib-eager: same, launched eagerly); torch = torch.distributed between two library calls. auto = lib, "
+                         "falling back in that order when this process launches the ranks itself")
+    ap.add_argument("--backend", default="nccl", help="--comm torch only: torch.distributed backend; nccl (= RCCL) is the product path, "
+                                                      "gloo rehearses the multi-rank logic on a box with fewer GPUs than ranks")
     ap.add_argument("--force-sharded", action="store_true", help="debug: drive the sharded (all-reduce) path even on one rank")
+    ap.add_argument("--launch-timeout", type=float, default=420.0, help="self-launched multi-GPU run: seconds before a mode is given up")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        # the driver's N = 1 form of the command with N > 1: be the launcher (no GPU call has happened in this process)
+        raise SystemExit(self_launch(args, sys.argv[1:]))
+    args.gpus = world
+    comm_mode = "lib" if args.comm == "auto" else args.comm
 
     # stdout carries exactly ONE line (the JSON record): libraries that chat on stdout (RCCL prints a
     # version banner at communicator creation) are sent to stderr for the whole run
@@ -100,44 +194,43 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    import numpy as np
     import torch
     import dopf_pkg
-    pkg = dopf_pkg.load()
+    dopf_pkg.load()
     from decentralopf_jl_amd import _capi, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
-        args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     local_rank %= max(1, torch.cuda.device_count())       # (ranks > GPUs only happens in a rehearsal on a small box)
     torch.cuda.set_device(local_rank)
     dist = None
     sharded = world > 1 or args.force_sharded
+    use_lib_comm = sharded and comm_mode in ("lib", "lib-eager")
     if sharded:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
-        if args.backend == "nccl":
+        if use_lib_comm:
+            # control plane only (unique id, demand sum, barriers, max of the times): gloo on host tensors.
+            # The data path — the per-iteration consensus sum — is the library's own RCCL communicator.
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        elif args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+    ctl_dev = "cpu" if (use_lib_comm or args.backend != "nccl") else "cuda"
 
-    idx, desc = WORKLOADS[args.workload]
+    desc = WORKLOADS[args.workload][1]
     # weak scaling: every rank owns one full grid of the workload (own seed), demand adds up
-    base = synth.baseline_config(idx, scale=args.scale * SHARE.get(args.workload, 1.0))
+    base = make_problem(synth, args.workload, args.scale)
+    own_demand = None
     if world > 1:
         cfg = dict(base.meta)
         pp = synth.synthetic_case(cfg["n_gen"], cfg["n_sto"], cfg["T"], N=cfg["N"], L=cfg["L"], seed=synth.SEED + rank)
         if cfg["L"] > 0:          # one network for everybody: rank 0's
             pp.ptdf, pp.f_max = base.ptdf, base.f_max * world
         own_demand = pp.demand.copy()
-        dem = torch.tensor(pp.demand, dtype=torch.float64, device="cuda")
+        dem = torch.tensor(pp.demand, dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(dem)
         pp.demand = dem.cpu().numpy()
     else:
@@ -149,6 +242,7 @@ def main():
     # its own, an all-on/all-off 2-cycle for more than a few dozen agents whatever gamma is; it has to shrink with the
     # number of agents like gamma does (0.3/A converges on the synthetic networks tried). Irrelevant on a copper plate.
     w_flow = args.w_flow if args.w_flow is not None else (10.0 if pp.L == 0 else 0.3 / A_global)
+    comm_info = None
 
     if not sharded:
         eng = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank,
@@ -156,12 +250,23 @@ def main():
                            **pp.engine_kwargs())
         step = lambda n: eng.iterate(n)
         sync = lambda: eng.sync()
+    elif use_lib_comm:
+        # every rank already holds its own grid; the library joins the ranks (RCCL) and owns the all-reduce
+        fl = args.flags | (_capi.F_NO_GRAPH if comm_mode == "lib-eager" else 0)
+        eng = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank, flags=fl,
+                                                                        n_agents_global=A_global), **pp.engine_kwargs())
+        box = [eng.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        eng.comm_init(world, rank, box[0])
+        step = lambda n: eng.iterate(n)
+        sync = lambda: eng.sync()
     else:
         from decentralopf_jl_amd.sharded import ShardedADMM
         # every rank already holds its own grid: a 1-way "shard" of its local problem, global agent count
         # passed explicitly; the all-reduce runs over all ranks on the engine's own stream
         sh = ShardedADMM(pp, 0, 1, gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank, n_agents_global_override=A_global)
-        st, tens = sh.stream, sh._tensor
+        tens = sh._tensor
 
         def _all_reduce():                # (ShardedADMM.step makes the engine's stream current around its loop)
             dist.all_reduce(tens, op=dist.ReduceOp.SUM)
@@ -185,20 +290,29 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     it_after, _ = sync()
     assert it_after == 1 + args.warmup + args.steps, (it_after, args.warmup, args.steps)
     fails = eng.solver_failures()
+    if use_lib_comm:
+        w_, r_, g_ = eng.comm_info()
+        comm_info = {"transport": "RCCL all-reduce issued by libdopf_hip (dopf_comm_init)", "world": w_,
+                     "captured_in_hipgraph": bool(g_)}
+    elif sharded:
+        comm_info = {"transport": f"torch.distributed ({args.backend}) all-reduce between dopf_local_update and dopf_apply_consensus",
+                     "world": world, "captured_in_hipgraph": False}
 
     # Per-kernel durations, live, HIP events on the stream the kernels run on. The timed region above replays
     # hipGraphs (no place for events), so the SAME iterations — W warm-up, then K — are run again on a fresh engine,
-    # the K launched kernel by kernel with an event pair around each: `timing` = mean over iterations W..W+K-1,
-    # `steady` = the last `timed_iters` of them (no cold-start or structure-change iterations left in there).
+    # the K launched kernel by kernel with an event pair around each: `timing` = mean over iterations W+1..W+K,
+    # `steady` = `timed_iters` iterations after iteration max(W+K, 200) (no cold-start or structure-change iterations
+    # left in there, whatever W and K are).
     # With N > 1 ranks the replay is rank 0's own grid as a single-GPU problem (its own demand, gamma = 1/A_local): the
     # kernels one GPU runs per iteration, without the collective.
     timing = steady = None
+    steady_from = 0
     if rank == 0:
         if world > 1:
             import copy
@@ -212,17 +326,18 @@ def main():
         er = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=g_r, w_flow=wf_r, eps=0.0, device=local_rank, flags=args.flags),
                           **ppr.engine_kwargs())
         er.iterate(args.warmup)
-        tail = max(1, min(args.timed_iters, args.steps))
-        parts, left = [], args.steps - tail
+        parts, left = [], args.steps
         while left > 0:
             n = min(left, 4096)
             parts.append(er.iterate_timed(n))
             left -= n
-        steady = er.iterate_timed(tail)
-        parts.append(steady)
         tot = sum(p_["iters"] for p_ in parts)
-        timing = {k: (sum(p_[k] * p_["iters"] for p_ in parts) / tot if k.endswith("_ms") else steady[k]) for k in steady}
+        timing = {k: (sum(p_[k] * p_["iters"] for p_ in parts) / tot if k.endswith("_ms") else parts[-1][k]) for k in parts[-1]}
         timing["iters"] = tot
+        steady_from = max(args.warmup + args.steps, 200)
+        if steady_from > args.warmup + args.steps:
+            er.iterate(steady_from - args.warmup - args.steps)
+        steady = er.iterate_timed(max(1, args.timed_iters))
         er.close()
 
     if rank == 0:
@@ -240,78 +355,84 @@ def main():
             "iters_per_sec": args.steps / dt,
             "updates_per_sec_per_gpu": A_local * args.steps / dt,
             "solver_failures": int(fails),
+            "timed_region": f"iterations {args.warmup + 1}..{args.warmup + args.steps} from the zero state (the run starts cold: the first "
+                            "~15 iterations re-shape every storage's contact structure and cost 1.5-3x a settled iteration)",
         }
+        if comm_info:
+            out["comm"] = comm_info
         if args.scale != 1.0:
             out["invalid"] = "scaled-down workload (debug run)"
         if timing is not None:
-            peak = 8000.0        # GB/s, HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
             # an event pair costs a fixed few microseconds even with nothing between (empty_ms): net it out
             k_ms = max(timing["gen_ms"] - timing["empty_ms"], 1e-6)
             fused = bool(timing.get("agents_fused"))
             pair = pp.L == 0 and pp.T % 2 == 0
-            if fused:       # ONE launch does every x-update: generators and storages
-                kname, alg_b = "k_agents", gen_b + sto_b + shared_b
-            else:
-                kname, alg_b = ("k_gen_update_pair" if pair else "k_gen_update"), gen_b + shared_b
-            ach = alg_b / (k_ms * 1e-3) / 1e9
-            traffic = None       # HBM bytes per launch from the committed PMC passes (scripts/profile.sh)
-            pmc_file = os.path.join(ROOT, "profiles", "r01_pmc.json")
-            if os.path.exists(pmc_file):
-                recs = json.load(open(pmc_file)).get(args.workload, {})
-                rec = next((r for k, r in sorted(recs.items()) if k.startswith(kname) and r.get("FETCH_SIZE") is not None), None)
-                if rec:        # gfx950: FETCH_SIZE counts half of a streaming read (MI355X_MICROARCH.md, HBM); unit KiB
-                    traffic = (2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0
-            ks_ms = max(steady["gen_ms"] - steady["empty_ms"], 1e-6)
-            out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": peak,
-                               "unit": "GB/s", "frac": ach / peak, "traffic": traffic,
-                               "algorithmic_bytes_per_launch": alg_b,
-                               "kernel_ms": k_ms, "kernel_ms_with_event_overhead": timing["gen_ms"],
-                               "window": f"mean over the timed region's iterations ({args.warmup}..{args.warmup + args.steps - 1} from the zero "
-                                         "state, replayed with events): includes the iterations in which storages fall back to the cold scan",
-                               "steady_state": {"kernel_ms": ks_ms, "achieved": alg_b / (ks_ms * 1e-3) / 1e9,
-                                                "frac": alg_b / (ks_ms * 1e-3) / 1e9 / peak,
-                                                "window": f"last {steady['iters']} iterations of that region"}}
-            if traffic is not None:
-                out["roofline"]["traffic_GBps"] = traffic / (k_ms * 1e-3) / 1e9
-                out["roofline"]["traffic_frac_of_peak"] = out["roofline"]["traffic_GBps"] / peak
             bs = 256 if fused else 512
             rows = bs // (pp.T // 2) if pair else 1
             row_skip = pair and not (args.flags & _capi.F_NO_ROW_SKIP) and max(rows, -(-pp.G // 2048)) >= 8 * rows    # as dopf_create decides
+            if fused:       # ONE launch does every x-update: generators and storages
+                kname, alg_b = "k_agents", gen_b + sto_b + shared_b
+            else:
+                kname = ("k_gen_update_pair_skip" if row_skip else "k_gen_update_pair") if pair else "k_gen_update"
+                alg_b = gen_b + shared_b
+            traffic = None       # HBM bytes per launch from the committed PMC passes (scripts/profile.sh)
+            for tag in ("r02", "r01"):
+                pmc_file = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
+                if traffic is None and os.path.exists(pmc_file):
+                    recs = json.load(open(pmc_file)).get(args.workload, {})
+                    rec = next((r for k, r in sorted(recs.items()) if k.startswith(kname) and r.get("FETCH_SIZE") is not None), None)
+                    if rec:        # gfx950: FETCH_SIZE counts half of a streaming read (MI355X_MICROARCH.md, HBM); unit KiB
+                        traffic = (2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0
+            ks_ms = max(steady["gen_ms"] - steady["empty_ms"], 1e-6)
+            # Row skipping moves fewer bytes than the 16T+20 B/update model: algorithmic bytes / time would exceed what the
+            # memory system did (and the 8 TB/s peak). The roofline fraction is then taken from the MEASURED traffic.
+            basis_b, basis = alg_b, "algorithmic bytes (SURVEY.md 8d model)"
+            if row_skip and traffic is not None:
+                basis_b, basis = traffic, ("measured HBM traffic (PMC): the kernel skips rows that provably stay on a bound, so the "
+                                           "model's bytes are not moved")
+            ach = basis_b / (k_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": PEAK_GBPS,
+                               "unit": "GB/s", "frac": ach / PEAK_GBPS, "traffic": traffic,
+                               "bytes_basis": basis,
+                               "algorithmic_bytes_per_launch": alg_b,
+                               "kernel_ms": k_ms, "kernel_ms_with_event_overhead": timing["gen_ms"],
+                               "window": f"mean over the timed region's iterations ({args.warmup + 1}..{args.warmup + args.steps} from the zero "
+                                         "state, replayed with HIP events on the kernels' stream)",
+                               "steady_state": {"kernel_ms": ks_ms, "achieved": basis_b / (ks_ms * 1e-3) / 1e9,
+                                                "frac": basis_b / (ks_ms * 1e-3) / 1e9 / PEAK_GBPS,
+                                                "window": f"{steady['iters']} iterations from iteration {steady_from + 1} on"}}
+            if row_skip:
+                out["roofline"]["algorithmic_GBps"] = alg_b / (k_ms * 1e-3) / 1e9
             if fused:
                 out["roofline"]["what"] = ("all x-updates of an iteration in one launch: generator blocks stream P (HBM bound), storage "
-                                           "blocks run the warm-started SoC solve (latency/VALU bound) on the same CUs")
-            if row_skip:
-                if not fused:
-                    out["roofline"]["kernel"] = "k_gen_update_pair_skip"
-                out["roofline"]["note"] = ("rows of P that sit on a bound for all timesteps and provably stay there are neither read nor "
-                                           "written (bit-identical results), so the launch moves fewer bytes than the 16T+20 B per-update "
-                                           "model: `achieved`/`frac` (algorithmic bytes / time) can exceed what `traffic` shows moved")
+                                           "blocks run the active-set SoC solve (fp64 VALU bound) on the same CUs")
             out["kernels_ms"] = {k: v for k, v in timing.items() if k.endswith("_ms")}
             out["kernels_ms_steady_state"] = {k: v for k, v in steady.items() if k.endswith("_ms")}
             out["agents_fused"] = fused
             if not fused:
                 s_ms = max(timing["sto_ms"] - timing["empty_ms"], 1e-6)
-                out["storage_kernel"] = {"kernel": "k_sto (warm start, then the cold scan for what it left over)" if pp.L == 0 else "k_sto_warm + k_sto_update", "bound": "fp64 VALU (segmented Newton + certificate; scan fallback), not HBM",
+                out["storage_kernel"] = {"kernel": "k_sto (active-set solve; scan kernel for what it leaves over)" if pp.L == 0 else "k_sto_warm + k_sto_update",
+                                         "bound": "fp64 VALU (segmented Newton + certificate), not HBM",
                                          "algorithmic_bytes_per_launch": sto_b, "kernel_ms": s_ms,
                                          "achieved_GBps": sto_b / s_ms * 1e-6}
             if fused and world == 1 and not args.force_sharded:
                 # the two halves of k_agents on their own (separate launches, DOPF_F_NO_FUSE), steady state: the generator
-                # sweep is the HBM-bound part, the storage solve the latency-bound one
+                # sweep is the HBM-bound part, the storage solve the VALU-bound one
                 ex = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank,
                                                                                flags=args.flags | _capi.F_NO_FUSE), **pp.engine_kwargs())
-                ex.iterate(args.warmup + args.steps - steady["iters"])
+                ex.iterate(steady_from)
                 tx = ex.iterate_timed(steady["iters"])
                 ex.close()
                 g_ms, s_ms2 = max(tx["gen_ms"] - tx["empty_ms"], 1e-6), max(tx["sto_ms"] - tx["empty_ms"], 1e-6)
                 out["roofline"]["parts_as_separate_launches"] = {
                     "k_gen_update_pair": {"kernel_ms": g_ms, "algorithmic_bytes_per_launch": gen_b + shared_b,
-                                          "achieved": (gen_b + shared_b) / g_ms * 1e-6, "frac": (gen_b + shared_b) / g_ms * 1e-6 / peak},
-                    "k_sto (warm start + cold scan)": {"kernel_ms": s_ms2, "algorithmic_bytes_per_launch": sto_b,
-                                                       "achieved": sto_b / s_ms2 * 1e-6, "frac": sto_b / s_ms2 * 1e-6 / peak},
-                    "window": f"iterations {args.warmup + args.steps - steady['iters']}..{args.warmup + args.steps - 1}, as the steady state above"}
+                                          "achieved": (gen_b + shared_b) / g_ms * 1e-6, "frac": (gen_b + shared_b) / g_ms * 1e-6 / PEAK_GBPS},
+                    "k_sto": {"kernel_ms": s_ms2, "algorithmic_bytes_per_launch": sto_b,
+                              "achieved": sto_b / s_ms2 * 1e-6, "frac": sto_b / s_ms2 * 1e-6 / PEAK_GBPS},
+                    "window": "as the steady state above"}
             whole = (gen_b + sto_b + shared_b) / (dt / args.steps) / 1e9
             out["whole_iteration_GBps"] = whole
-            out["whole_iteration_frac_of_peak"] = whole / peak
+            out["whole_iteration_frac_of_peak"] = whole / PEAK_GBPS
         if not sharded:
             # the other half of BASELINE's metric: wall time until every |dual change| < 1e-3, from the zero state
             budget = int(max(64, min(100000, 10.0 * args.steps / dt)))     # at most ~10 s of iterations
@@ -341,27 +462,65 @@ def main():
         if not sharded and not args.no_also and args.scale == 1.0:
             # the other BASELINE configurations that fit one GPU, same engine, short runs (reported, not the metric)
             also = []
-            for wl in ("config1", "config4", "config2", "config3-share"):
+            for wl in ("config1", "config4", "config2", "config3-share", "config3"):
                 if wl == args.workload:
                     continue
-                ppx = synth.baseline_config(WORKLOADS[wl][0], scale=SHARE.get(wl, 1.0))
+                ppx = make_problem(synth, wl)
                 Ax = ppx.G + ppx.S
                 ex = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=1.0 / Ax, w_flow=10.0 if ppx.L == 0 else 0.3 / Ax,
                                                                                eps=0.0, device=local_rank),
                                   **ppx.engine_kwargs())
-                ex.iterate(args.warmup)
+                wx = max(args.warmup, 48)
+                ex.iterate(wx)
                 torch.cuda.synchronize()
+                nx = 200 if wl != "config3" else 100
                 t0 = time.perf_counter()
-                ex.iterate(200)
+                ex.iterate(nx)
                 tx = time.perf_counter() - t0
                 gb, sb, shb = algorithmic_bytes(ppx.G, ppx.S, ppx.T, ppx.N, ppx.L)
-                also.append({"workload": wl, "agents": Ax, "timesteps": ppx.T, "iters_per_sec": 200 / tx,
-                             "agent_updates_per_sec": Ax * 200 / tx, "ms_per_step": 1e3 * tx / 200,
-                             "whole_iteration_GBps": (gb + sb + shb) / (tx / 200) / 1e9})
+                also.append({"workload": wl, "agents": Ax, "timesteps": ppx.T, "iters_per_sec": nx / tx,
+                             "agent_updates_per_sec": Ax * nx / tx, "ms_per_step": 1e3 * tx / nx,
+                             "whole_iteration_GBps": (gb + sb + shb) / (tx / nx) / 1e9,
+                             "window": f"iterations {wx + 1}..{wx + nx}"})
                 ex.close()
+            # BASELINE configs[1] names "rho = 1.0" (rho there = the reference's gamma): the iteration RATE with that literal
+            # penalty (it does not converge at this size: Jacobi with a fixed prox weight)
+            pp1 = make_problem(synth, "config1")
+            ex = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=1.0, eps=1e-3, device=local_rank), **pp1.engine_kwargs())
+            ex.iterate(48)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            d1, c1 = ex.iterate(400)
+            tx = time.perf_counter() - t0
+            also.append({"workload": "config1, literal gamma = 1.0 (BASELINE's rho)", "agents": pp1.G + pp1.S, "timesteps": pp1.T,
+                         "iters_per_sec": d1 / tx, "agent_updates_per_sec": (pp1.G + pp1.S) * d1 / tx, "ms_per_step": 1e3 * tx / max(d1, 1),
+                         "converged": bool(c1), "lambda_residual_after_448": ex.get_residuals()[0],
+                         "note": "oscillates: every agent answers the same imbalance, aggregate gain ~ A*gamma/(1+gamma)"})
+            ex.close()
             out["also"] = also
+            # BASELINE configs[4] asks for a penalty sweep on the 1M-agent grid: iterations / seconds to the 1e-3 residual
+            pp4 = make_problem(synth, "config4")
+            A4 = pp4.G + pp4.S
+            sweep = []
+            for m in (0.3, 1.0, 1.5, 3.0):
+                cap = 2500
+                ex = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=m / A4, eps=1e-3, max_iters=cap, device=local_rank),
+                                  **pp4.engine_kwargs())
+                ex.iterate(0)
+                t0 = time.perf_counter()
+                dn, cv = 0, False
+                while not cv and dn < cap:
+                    d_, cv = ex.iterate(min(64, cap - dn))
+                    dn += d_
+                    if d_ == 0:
+                        break
+                tx = time.perf_counter() - t0
+                sweep.append({"gamma_times_A": m, "iterations": dn, "converged": bool(cv), "seconds": tx, "iters_per_sec": dn / tx})
+                ex.close()
+            out["config4_penalty_sweep"] = {"agents": A4, "timesteps": pp4.T, "stop_test": "all |dual change| < 1e-3", "iteration_cap": 2500,
+                                            "rows": sweep}
         if not sharded and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pp, gamma, w_flow)
+            out["cpu_baseline"] = cpu_baseline(pp, gamma, w_flow, synth)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()

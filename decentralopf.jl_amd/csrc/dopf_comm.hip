@@ -93,7 +93,7 @@ namespace dopf {
 int comm_enqueue_allreduce(dopf_ctx *c)
 {
     dopf_comm_state *cs = c->comm;
-    if (!cs || cs->host_sum || cs->world == 1) return DOPF_OK;       // (host transport: dopf_multi_iterate adds)
+    if (!cs || cs->host_sum) return DOPF_OK;       // (host transport: dopf_multi_iterate adds)
     const size_t n = (size_t)c->v.N * c->v.T + 2 * (size_t)c->v.L * c->v.T + 1;
     const ncclResult_t r = g_rccl.AllReduce(c->v.cons, c->v.cons, n, ncclDouble, ncclSum, cs->comm, c->main);
     if (r != ncclSuccess) return fail(c, DOPF_E_DEVICE, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
