@@ -31,9 +31,20 @@ from .network import Generator, Line, Node, Storage, pack
 
 
 @dataclass
+class PenaltyTerm:
+    """src/structures/penalty_terms.jl:1-5 (diagnostics: never read back by the algorithm)"""
+    energy_balance: np.ndarray
+    upper_flow: np.ndarray
+    lower_flow: np.ndarray
+
+
+@dataclass
 class ResultGenerator:
     generator: Generator
     generation: np.ndarray
+    penalty_term: Optional[PenaltyTerm] = None      # filled with ADMM(..., record_slacks=True)
+    U: Optional[np.ndarray] = None                  # (L, T)
+    K: Optional[np.ndarray] = None
 
 
 @dataclass
@@ -42,6 +53,9 @@ class ResultStorage:
     discharge: np.ndarray
     charge: np.ndarray
     level: np.ndarray
+    penalty_term: Optional[PenaltyTerm] = None
+    U: Optional[np.ndarray] = None
+    K: Optional[np.ndarray] = None
 
 
 @dataclass
@@ -62,12 +76,14 @@ class Result:
 
 @dataclass
 class Convergence:
+    """src/structures/convergence.jl:1-20. With history recording the *_res lists hold the reference's vectors /
+    matrices |dual change| per entry; without it their inf-norms (floats)."""
     lambda_: bool = False
-    lambda_res: List[float] = field(default_factory=list)
+    lambda_res: list = field(default_factory=list)
     mue: bool = False
-    mue_res: List[float] = field(default_factory=list)
+    mue_res: list = field(default_factory=list)
     rho: bool = False
-    rho_res: List[float] = field(default_factory=list)
+    rho_res: list = field(default_factory=list)
     all: bool = False
 
 
@@ -76,7 +92,8 @@ class ADMM:
 
     def __init__(self, gamma: float, nodes: Sequence[Node], generators: Sequence[Generator],
                  storages: Sequence[Storage], lines: Sequence[Line], *, backend: Optional[_capi.CApi] = None,
-                 record: bool = True, max_iters: int = 0, backend_mode: Optional[int] = None, **params):
+                 record: bool = True, max_iters: int = 0, backend_mode: Optional[int] = None,
+                 record_slacks: bool = False, **params):
         self.iteration = 1
         self.gamma = float(gamma)
         self.nodes, self.generators = list(nodes), list(generators)
@@ -100,6 +117,7 @@ class ADMM:
         for u in self.generators + self.storages:
             self.node_to_units.setdefault(id(u.node), []).append(u)
         self.record = record
+        self.record_slacks = record_slacks        # also fetch every unit's U, K and PenaltyTerm (diagnostics, HIP backend)
         self.params = _capi.default_params(gamma=self.gamma, max_iters=max_iters, **params)
         self.engine = _capi.Engine(backend if backend is not None else _capi.hip_api(),
                                    params=self.params, mode=backend_mode, **p.engine_kwargs())
@@ -109,10 +127,20 @@ class ADMM:
         P, D, C, E = self.engine.get_primal()
         inj, aU, aK, flow, cost = self.engine.get_consensus()
         u2r: Dict[int, object] = {}
+        prev = self.results[-1] if self.results else None
+        G = len(self.generators)
+
+        def extras(a, delta):
+            if not self.record_slacks:
+                return {}
+            U, K = self.engine.get_agent_slacks(a)
+            return dict(U=U, K=K, penalty_term=PenaltyTerm(*self.engine.get_agent_penalty(a, delta=delta)))
         for i, g in enumerate(self.generators):
-            u2r[id(g)] = ResultGenerator(g, P[i].copy())
+            d = P[i] - (prev.of(g).generation if prev else 0.0)
+            u2r[id(g)] = ResultGenerator(g, P[i].copy(), **extras(i, d))
         for i, s in enumerate(self.storages):
-            u2r[id(s)] = ResultStorage(s, D[i].copy(), C[i].copy(), E[i].copy())
+            q0 = (prev.of(s).discharge - prev.of(s).charge) if prev else 0.0
+            u2r[id(s)] = ResultStorage(s, D[i].copy(), C[i].copy(), E[i].copy(), **extras(G + i, (D[i] - C[i]) - q0))
         T = self.packed.T
         return Result(u2r, P.sum(axis=0) if P.size else np.zeros(T), D.sum(axis=0) if D.size else np.zeros(T),
                       C.sum(axis=0) if C.size else np.zeros(T), aU, aK, cost, inj, flow)
@@ -122,9 +150,14 @@ class ADMM:
         _, conv = self.engine.sync()
         if done and (self.iteration != 1 or done > 1):
             c = self.convergence
-            c.lambda_res.append(lam_res)
-            c.mue_res.append(mu_res)
-            c.rho_res.append(rho_res)
+            if self.record and len(self.lambdas) >= 2:       # the reference's per-entry residuals (convergence.jl:5-12)
+                c.lambda_res.append(np.abs(self.lambdas[-1] - self.lambdas[-2]))
+                c.mue_res.append(np.abs(self.mues[-1] - self.mues[-2]))
+                c.rho_res.append(np.abs(self.rhos[-1] - self.rhos[-2]))
+            else:
+                c.lambda_res.append(lam_res)
+                c.mue_res.append(mu_res)
+                c.rho_res.append(rho_res)
             eps = self.params.eps
             c.lambda_, c.mue, c.rho = lam_res < eps, mu_res < eps, rho_res < eps
         self.convergence.all = bool(conv)

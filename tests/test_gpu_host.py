@@ -69,3 +69,51 @@ def test_sharded_driver_with_rccl_allreduce_world1(hip_api):
             assert np.array_equal(a[k], b[k]), k
     finally:
         dist.destroy_process_group()
+
+
+def test_export_results_on_hip_matches_reference_dump(three_node, golden, tmp_path):
+    """Every row of the three CSVs written from a HIP run against the reference's own dump (results/TNS_*.csv, kept
+    iterations), in the reference's row order (src/helpers/output.jl:14-85: lambda, rho, mue; charge before discharge)."""
+    import csv
+    nodes, lines, gens, stos, _ = three_node
+    admm = pkg.ADMM(0.3, nodes, gens, stos, lines, eps=0.0, max_iters=12, record_slacks=True)
+    pkg.run(admm)
+    pkg.export_results(admm, "TNS", parent_dir=str(tmp_path) + "/")
+    gold = golden["TNS"]["iterations"]
+    n_it = 12
+    rows = list(csv.reader(open(tmp_path / "TNS_duals.csv")))
+    assert rows[0] == ["iteration", "dual", "timestep", "line", "value"] and len(rows) == 1 + n_it * 2 * (1 + 3 + 3)
+    order = [(name, i, t, l) for name, nl in (("lambda", 0), ("rho", 3), ("mue", 3)) for i in range(1, n_it + 1)
+             for t in (1, 2) for l in (range(1, nl + 1) if nl else [""])]
+    checked = 0
+    for r, (name, i, t, l) in zip(rows[1:], order):
+        assert r[:4] == [str(i), name, str(t), str(l)]
+        if str(i) in gold:
+            g = gold[str(i)]
+            want = g["lam"][t - 1] if name == "lambda" else g["mu" if name == "mue" else "rho"][l - 1][t - 1]
+            assert abs(float(r[4]) - want) < 1e-5
+            checked += 1
+    assert checked >= 10 * 14
+    rows = list(csv.reader(open(tmp_path / "TNS_generators.csv")))
+    assert rows[0] == ["iteration", "generator", "timestep", "generation"] and len(rows) == 1 + 4 * n_it * 2
+    k = 1
+    for gi, g in enumerate(gens):
+        for i in range(1, n_it + 1):
+            for t in (1, 2):
+                assert rows[k][:3] == [str(i), g.name, str(t)]
+                if str(i) in gold:
+                    assert abs(float(rows[k][3]) - gold[str(i)]["P"][gi][t - 1]) < 1e-5
+                k += 1
+    rows = list(csv.reader(open(tmp_path / "TNS_storages.csv")))
+    assert rows[0] == ["iteration", "storage", "timestep", "charge", "discharge"] and len(rows) == 1 + n_it * 2
+    k = 1
+    for i in range(1, n_it + 1):
+        for t in (1, 2):
+            assert rows[k][:3] == [str(i), "battery", str(t)]
+            if str(i) in gold:
+                assert abs(float(rows[k][3]) - gold[str(i)]["C"][t - 1]) < 1e-5 and abs(float(rows[k][4]) - gold[str(i)]["D"][t - 1]) < 1e-5
+            k += 1
+    # the per-unit diagnostics of ResultGenerator / ResultStorage (results.jl:1-17) came along
+    r = admm.results[-1].of(gens[0])
+    assert r.U.shape == (3, 2) and r.K.shape == (3, 2) and r.penalty_term.energy_balance.shape == (2,)
+    assert len(admm.convergence.lambda_res) == 11 and admm.convergence.mue_res[-1].shape == (3, 2)

@@ -260,6 +260,36 @@ def test_hip_full_size_properties(hip_api, name, idx, scale):
     assert e.solver_failures() == 0
 
 
+def test_hip_full_size_continuous_storage_parameters(hip_api):
+    """config2's size with storages drawn from continuous ranges (marginal cost, power and the level/power ratio all
+    different per storage): no two storages share a contact structure, unlike the 48 lock-stepped integer types of the
+    synthetic generator. Every storage must carry a KKT certificate every iteration and none may reach the scan kernel's
+    iteration cap."""
+    pp = synth.baseline_config(2)
+    rng = np.random.default_rng(77)
+    pp.sto_mc = rng.uniform(0.5, 3.5, pp.S)
+    pp.sto_pmax = rng.uniform(5.0, 20.0, pp.S)
+    pp.sto_emax = pp.sto_pmax * rng.uniform(0.7, 4.0, pp.S)
+    gamma = 1.0 / (pp.G + pp.S)
+    e = make_engine(hip_api, pp, eps=0.0, gamma=gamma)
+    left_total = 0
+    for n in (1, 1, 1, 3, 9, 25, 60):
+        e.iterate(n - 1)
+        before = state_of(e)
+        e.iterate(1)
+        after = state_of(e)
+        lam_used = e.get_duals_used()[0]
+        s_prev = before["inj"].sum(axis=0)
+        D, C, E = after["D"], after["C"], after["E"]
+        assert E.min() >= -1e-9 and (E - pp.sto_emax[:, None]).max() <= 1e-9
+        assert np.abs(np.cumsum(C - D, axis=1) - E).max() < 1e-9
+        theta = lam_used[None, :] + gamma * (s_prev[None, :] - (before["D"] - before["C"]))
+        assert storage_kkt_violation(pp, np.arange(pp.S), before["D"], before["C"], D, C, E, theta, gamma) < 1e-6
+        left_total += e.warm_start_stats()[1]
+    assert e.solver_failures() == 0
+    assert left_total <= 0.01 * pp.S, left_total          # the active-set body certifies (almost) everything itself
+
+
 @pytest.mark.parametrize("case", ["config1", "config2/5", "config4/5", "340k+2k x24 (fused and row skipping)"])
 def test_hip_fused_agents_match_separate_launches(hip_api, case):
     """k_agents (one launch for generators + storages) against the separate kernels: same iterates up to the
