@@ -183,8 +183,32 @@ void launch_tables(const DevView &v, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------
-// slack sums (L > 0): one block per (n,t), threads <-> lines, agents staged through LDS
+// slack sums (L > 0)
 // ------------------------------------------------------------------------------------------------
+// sum over the agents a of node n of U_a[l,t] = max(0, aU - kap d_a) (and K_a = max(0, aK + kap d_a)), d_a = the agent's
+// injection change, |d_a| <= W_n. With reach = |kap| W_n three cases per (n, l, t):
+//     aU - reach >= 0   every agent's slack is active:   sum = n_a aU - kap sum_a d_a      (closed form from the node's sum)
+//     aU + reach <= 0   none is:                         sum = 0
+//     otherwise         the agents are walked one by one (k_slack, agents staged in LDS) and the sum is stored
+// Only the third kind — a line whose switch point lies inside the window of what the node's agents can do — travels
+// through memory (part_U / part_K); k_reduce re-derives the case with the same arithmetic and adds the closed forms
+// itself from the N x T node sums. (Round 1 wrote all N x L x T entries and read them back: 130 MB per iteration on
+// the 118-node share against 40 MB of algorithmic traffic.)
+struct SlackCase {
+    double aU, aK, kap, reach;
+};
+
+__device__ __forceinline__ SlackCase slack_case(double g, double w2, double inv, double h, double f, double F, double cu, double ck, double W)
+{
+#pragma clang fp contract(off)          // the two kernels must classify identically: no fused multiply-adds here
+    SlackCase c;
+    c.aU = (g * cu - w2 * (f - F)) * inv;
+    c.aK = (g * ck + w2 * (f + F)) * inv;
+    c.kap = w2 * h * inv;
+    c.reach = fabs(c.kap) * W;
+    return c;
+}
+
 // sum_a max(0, base + k d_a) over the node's agents at one timestep: the staged ones from LDS, eight reads in
 // flight, the rest (nodes with more agents than the tile holds) from memory; list order
 __device__ __forceinline__ double walk_sum(const DevView &v, const double *dtile, int tt, int t, int T, int gb, int ng,
@@ -249,10 +273,16 @@ __global__ __launch_bounds__(256) void k_slack(DevView v, const int cap)
             double sum = 0.0;
             for (int q = 0; q < 8; ++q) sum += red[q * 32 + tt];
             sumD[tt] = sum;
+            if (t < T) v.node_dsum[n + (size_t)N * t] = sum;
         }
         __syncthreads();
     }
     const int nt = min(TS, T - t0), np = L * nt;
+    {   // usually no (line, timestep) of this chunk has a switch point within anybody's reach: the node sums were all
+        int any = 0;
+        if (tid < nt) any = v.walk_any[t0 + tid];
+        if (!__syncthreads_or(any)) return;
+    }
     for (int p0 = tid; p0 < np; p0 += 4 * 256) {          // pairs (l fastest: coalesced), four per lane in flight
         double h[4], f[4], F[4], cu[4], ck[4];
         int ls[4], tts[4];
@@ -268,19 +298,14 @@ __global__ __launch_bounds__(256) void k_slack(DevView v, const int cap)
         for (int u = 0; u < 4; ++u) {
             if (p0 + 256 * u >= np) continue;
             const int l = ls[u], tt = tts[u], t = t0 + tt;
-            const double aU = (g * cu[u] - w2 * (f[u] - F[u])) * inv;
-            const double aK = (g * ck[u] + w2 * (f[u] + F[u])) * inv;
-            const double kap = w2 * h[u] * inv, reach = fabs(kap) * W, sD = sumD[tt];
-            double sU = 0.0, sK = 0.0;
-            if (aU - reach >= 0.0) sU = na * aU - kap * sD;       // max(0, aU - kap d) = aU - kap d for all agents
-            else if (aU + reach > 0.0)                            // (else 0 for all agents)
-                sU = walk_sum(v, dtile, tt, t, T, gb, ng, sb, na, cap, aU, -kap);
-            if (aK - reach >= 0.0) sK = na * aK + kap * sD;
-            else if (aK + reach > 0.0)
-                sK = walk_sum(v, dtile, tt, t, T, gb, ng, sb, na, cap, aK, kap);
+            if (!v.walk_flag[l + L * t]) continue;            // k_reduce takes the dot-product form
+            const SlackCase c = slack_case(g, w2, inv, h[u], f[u], F[u], cu[u], ck[u], W);
             const size_t at = (size_t)n + (size_t)N * t;
-            v.part_U[at * L + l] = sU;
-            v.part_K[at * L + l] = sK;
+            // (closed-form and all-zero cases: k_reduce adds them from node_dsum)
+            if (!(c.aU - c.reach >= 0.0) && c.aU + c.reach > 0.0)
+                v.part_U[at * L + l] = walk_sum(v, dtile, tt, t, T, gb, ng, sb, na, cap, c.aU, -c.kap);
+            if (!(c.aK - c.reach >= 0.0) && c.aK + c.reach > 0.0)
+                v.part_K[at * L + l] = walk_sum(v, dtile, tt, t, T, gb, ng, sb, na, cap, c.aK, c.kap);
         }
     }
 }
@@ -290,6 +315,15 @@ void launch_slack(const DevView &v, hipStream_t s)
     if (v.L == 0) return;
     const int cap = std::min(v.maxNodeAgents, 224);         // 224 agents x 33 doubles = 58 KB (+ 2.3 KB static: under 64 KB)
     hipLaunchKernelGGL(k_slack, dim3(v.N * ((v.T + 31) / 32)), dim3(256), (size_t)cap * 33 * sizeof(double), s, v, cap);
+}
+
+// does the slack sum of (line, timestep) need the per-node cases? Not if the offsets clear the line's largest reach on
+// either side for U and for K: then every agent of every node has the slack active (sum = dot product) or inactive (0)
+__device__ __forceinline__ bool slack_needs_cases(double g, double w2, double inv, double f, double F, double cu, double ck, double R)
+{
+    const SlackCase c = slack_case(g, w2, inv, 0.0, f, F, cu, ck, 0.0);
+    const bool uOk = c.aU - R >= 0.0 || c.aU + R <= 0.0, kOk = c.aK - R >= 0.0 || c.aK + R <= 0.0;
+    return !(uOk && kOk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -404,34 +438,108 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
             if (tid == 0) v.reduce_ticket[n * TC + tcx] = 0;       // ready for the next iteration
         }
     } else {
-        const size_t LT = (size_t)L * T;
-        const size_t idx = (size_t)(blockIdx.x - N * RB * TC) * 256 + tid;
-        if (idx < 2 * LT) {
-            const int which = idx >= LT;
-            const size_t rem = idx - which * LT;            // l + L*t
-            const int l = (int)(rem % L), t = (int)(rem / L);
-            const double *src = which ? v.part_K : v.part_U;
+        // slack sums: one block per (timestep, U|K); the node sums of the timestep and the nodes' constants are staged
+        // in LDS, a thread owns a line and walks the nodes in a fixed order (eight ptdf loads in flight)
+        extern __shared__ double nsh[];               // [N] node sums of timestep t | [N] window | [N] agents at the node
+        double *sdL = nsh, *winL = nsh + N, *naL = nsh + 2 * N;
+        const int b2 = blockIdx.x - N * RB * TC, t = b2 >> 1, which = b2 & 1;
+        if (v.dbg & 1) return;
+        for (int n = tid; n < N; n += 256) {
+            sdL[n] = v.node_dsum[n + (size_t)N * t];
+            winL[n] = v.node_win[n];
+            naL[n] = (double)((v.node_gen_beg[n + 1] - v.node_gen_beg[n]) + (v.node_sto_beg[n + 1] - v.node_sto_beg[n]));
+        }
+        __syncthreads();
+        const double *src = which ? v.part_K : v.part_U;
+        const double w2 = 2.0 * v.w_flow, g = v.gamma, inv = 1.0 / (w2 + g);
+        for (int l = tid; l < L; l += 256) {
+            const size_t rem = l + (size_t)L * t;
+            const double f = v.flow[rem], F = v.fmax[l], cu = v.avgU[rem], ck = v.avgK[rem];
+            if (!v.walk_flag[rem]) {
+                // every agent of every node has this slack active, or none has: sum_a (aX -+ kap_n d_a) = A aX -+ (w2 inv) sum_n h_n D_n
+                const SlackCase c0 = slack_case(g, w2, inv, 0.0, f, F, cu, ck, 0.0);
+                const double a = which ? c0.aK : c0.aU;
+                double out = 0.0;
+                if (a > 0.0) {
+                    double dot = 0.0, cnt = 0.0;
+                    for (int n0 = 0; n0 < N; n0 += 8) {
+                        double h[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) h[u] = n0 + u < N ? v.ptdf[l + (size_t)L * (n0 + u)] : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (n0 + u < N) { dot += h[u] * sdL[n0 + u]; cnt += naL[n0 + u]; }
+                    }
+                    out = which ? cnt * a + (w2 * inv) * dot : cnt * a - (w2 * inv) * dot;
+                }
+                v.cons[(size_t)N * T + (size_t)which * L * T + rem] = out;
+                continue;
+            }
+            // pass 1, all nodes in order: closed forms are added at once, the nodes k_slack had to walk are remembered in a
+            // bit mask (a load whose address hangs on this arithmetic would put two dependent memory round trips into
+            // every batch); pass 2 fetches the walked sums, eight in flight. Both orders are fixed: deterministic.
+            constexpr int MW = 8;                              // mask words: up to 256 nodes (more: walked inline below)
+            unsigned wm[MW];
+#pragma unroll
+            for (int q = 0; q < MW; ++q) wm[q] = 0u;
             double sum = 0.0;
-            for (int n0 = 0; n0 < N; n0 += 8) {           // eight loads in flight (a plain loop waits for each one)
-                double x[8];
+            double hn[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) hn[u] = v.ptdf[l + (size_t)L * (u < N ? u : N - 1)];
+            for (int n0 = 0; n0 < ((v.dbg & 2) ? 8 : N); n0 += 8) {
+                double h[8], x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) h[u] = hn[u];
+                if (n0 + 8 < N) {                              // next batch's rows are on their way while this one is worked
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) hn[u] = v.ptdf[l + (size_t)L * (n0 + 8 + u < N ? n0 + 8 + u : N - 1)];
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int n = n0 + u;
-                    x[u] = n < N ? src[((size_t)n + (size_t)N * t) * L + l] : 0.0;
+                    const int n = n0 + u < N ? n0 + u : N - 1;
+                    const SlackCase c = slack_case(g, w2, inv, h[u], f, F, cu, ck, winL[n]);
+                    const double a = which ? c.aK : c.aU;
+                    const bool live = n0 + u < N, all_on = a - c.reach >= 0.0, walked = live && !all_on && a + c.reach > 0.0;
+                    x[u] = (live && all_on) ? (which ? naL[n] * c.aK + c.kap * sdL[n] : naL[n] * c.aU - c.kap * sdL[n]) : 0.0;
+                    if (walked) {
+                        if (n < 32 * MW) {
+#pragma unroll
+                            for (int q = 0; q < MW; ++q)
+                                if (q == (n >> 5)) wm[q] |= 1u << (n & 31);
+                        } else {
+                            x[u] = src[((size_t)n + (size_t)N * t) * L + l];
+                        }
+                    }
                 }
                 sum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
             }
-            v.cons[(size_t)N * T + idx] = sum;
+#pragma unroll
+            for (int q = 0; q < MW; ++q) {
+                unsigned m = wm[q];
+                while (m) {
+                    double x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        x[u] = 0.0;
+                        if (m) {
+                            const int n = 32 * q + __builtin_ctz(m);
+                            m &= m - 1u;
+                            x[u] = src[((size_t)n + (size_t)N * t) * L + l];
+                        }
+                    }
+                    sum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+                }
+            }
+            v.cons[(size_t)N * T + (size_t)which * L * T + rem] = sum;
         }
     }
 }
 
 void launch_reduce(const DevView &v, hipStream_t s)
 {
-    const size_t LT2 = 2 * (size_t)v.L * v.T;
     const int TC = (v.T + 31) / 32;
-    const int blocks = v.N * v.reduceRB * TC + (int)((LT2 + 255) / 256);
-    hipLaunchKernelGGL(k_reduce, dim3(blocks), dim3(256), 0, s, v);
+    const int blocks = v.N * v.reduceRB * TC + (v.L > 0 ? 2 * v.T : 0);
+    hipLaunchKernelGGL(k_reduce, dim3(blocks), dim3(256), v.L > 0 ? 3 * (size_t)v.N * sizeof(double) : 0, s, v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -500,6 +608,12 @@ __device__ __forceinline__ void dual_body(const DevView &v, size_t i, double &rl
             v.mu[i] = mn; v.rho[i] = rn;
             rm = fmax(rm, fabs(mn - mo));
             rr = fmax(rr, fabs(rn - ro));
+        }
+        {   // what the next slack sums of (l,t) will need (k_slack / k_reduce)
+            const double w2 = 2.0 * v.w_flow, inv = 1.0 / (w2 + v.gamma);
+            const int need = slack_needs_cases(v.gamma, w2, inv, f, v.fmax[l], v.avgU[i], v.avgK[i], v.line_reach[l]) ? 1 : 0;
+            v.walk_flag[i] = need;
+            if (need) atomicOr(&v.walk_any[t], 1);          // (zeroed by the caller before the sweep; an OR has no order)
         }
     }
 }
@@ -611,6 +725,7 @@ __global__ __launch_bounds__(256) void k_dual_t(DevView v)
             rl = fabs(ln - lo);
         }
     }
+    int anyNeed = 0;
     for (int l = tid; l < L; l += 256) {
         double f = 0.0;
         for (int n0 = 0; n0 < N; n0 += 8) {                                  // eight rows of ptdf in flight
@@ -635,7 +750,15 @@ __global__ __launch_bounds__(256) void k_dual_t(DevView v)
             rm = fmax(rm, fabs(mn - mo));
             rr = fmax(rr, fabs(rn - ro));
         }
+        {   // what the next slack sums of (l,t) will need (k_slack / k_reduce)
+            const double w2 = 2.0 * v.w_flow, inv = 1.0 / (w2 + v.gamma);
+            const int need = slack_needs_cases(v.gamma, w2, inv, f, v.fmax[l], v.avgU[i], v.avgK[i], v.line_reach[l]) ? 1 : 0;
+            v.walk_flag[i] = need;
+            anyNeed |= need;
+        }
     }
+    anyNeed = __syncthreads_or(anyNeed);
+    if (tid == 0 && L > 0) v.walk_any[t] = anyNeed ? 1 : 0;
     if (UPDATE) {
         // block max (order independent), then one atomic per block and residual
         __syncthreads();
@@ -753,6 +876,10 @@ __global__ __launch_bounds__(256) void k_dual_price_small(DevView v)
         __syncthreads();
     }
     double rl = 0.0, rm = 0.0, rr = 0.0;
+    if (v.L > 0) {
+        for (int t = tid; t < v.T; t += 256) v.walk_any[t] = 0;
+        __syncthreads();
+    }
     for (size_t i = tid; i < n1; i += 256) dual_body<UPDATE>(v, i, rl, rm, rr);
     if (UPDATE) {
         red[0][tid] = rl; red[1][tid] = rm; red[2][tid] = rr;
@@ -786,6 +913,7 @@ void launch_dual(const DevView &v, hipStream_t s)
         hipLaunchKernelGGL(k_price_t<true>, dim3(v.T), dim3(256), (size_t)v.L * sizeof(double), s, v);
         return;
     }
+    if (v.L > 0) hipMemsetAsync(v.walk_any, 0, sizeof(int) * v.T, s);
     hipLaunchKernelGGL(k_dual<true>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_price<true>, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, v);
 }
@@ -834,6 +962,7 @@ void launch_derive(const DevView &v, hipStream_t s, bool from_primal)
         hipLaunchKernelGGL(k_price_t<false>, dim3(v.T), dim3(256), (size_t)v.L * sizeof(double), s, v);
         return;
     }
+    if (v.L > 0) hipMemsetAsync(v.walk_any, 0, sizeof(int) * v.T, s);
     hipLaunchKernelGGL(k_dual<false>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, v);
     hipLaunchKernelGGL(k_price<false>, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, v);
 }
