@@ -366,7 +366,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         TRY(dev_alloc(c, &v.tb_slope, NT * (v.M2 + 1))); TRY(dev_alloc(c, &v.tb_psi0, NT));
         TRY(dev_alloc(c, &v.tb_m, NT));
         TRY(dev_alloc(c, &v.part_U, NT * L)); TRY(dev_alloc(c, &v.part_K, NT * L)); TRY(dev_alloc(c, &v.node_dsum, NT));
-        TRY(dev_alloc(c, &v.walk_flag, LT)); TRY(dev_alloc(c, &v.walk_any, T));
+        TRY(dev_alloc(c, &v.walk_flag, LT)); TRY(dev_alloc(c, &v.walk_any, T)); TRY(dev_alloc(c, &v.tab_skip, T));
     }
     TRY(dev_alloc(c, &v.part_ginj, (size_t)v.nGenItems * T)); TRY(dev_alloc(c, &v.part_gcost, v.nGenItems));
     TRY(dev_alloc(c, &v.part_sinj, (size_t)v.nStoItems * T)); TRY(dev_alloc(c, &v.part_scost, v.nStoItems));

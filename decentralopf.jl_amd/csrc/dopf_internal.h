@@ -85,6 +85,7 @@ struct DevView {
     double *part_U, *part_K;                        // [(n + N*t)*L + l]: only the entries k_slack had to walk agent by agent
     double *node_dsum;                              // [n + N*t] sum of the node's agents' injection changes (L > 0)
     const double *line_reach;                       // [l] max over nodes of |kap| W_n: beyond it no agent of any node can flip the line's slack
+    int *tab_skip;                                  // [t] the price kernel has written the (empty) tables of timestep t
     int *walk_flag, *walk_any;                      // [l + L*t], [t]: the slack sums of (l,t) need the per-node cases (set by the dual step)
     double *part2, *part2_cost;                     // [(n*RB + rb)*T + t], [rb]
     int *reduce_ticket;                             // [n]

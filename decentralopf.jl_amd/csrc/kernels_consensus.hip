@@ -71,6 +71,7 @@ __global__ __launch_bounds__(64) void k_tables(DevView v)
     const int lane = threadIdx.x;
     const size_t at = blockIdx.x;
     const int n = (int)(at % N), t = (int)(at / N);
+    if (v.tab_skip[t]) return;               // linear inside every window: the price kernel wrote Psi(0) and the slope
     const double w2 = 2.0 * v.w_flow, g = v.gamma, act = g / (w2 + g);
     const double W = v.node_win[n];
 
@@ -702,7 +703,10 @@ __global__ __launch_bounds__(256) void k_dual_t(DevView v)
     if (UPDATE && v.st->halt) return;
     extern __shared__ double q[];            // N
     __shared__ double red[256];
-    const int tid = threadIdx.x, t = blockIdx.x;
+    // block (timestep t, group of 64 lines): thread (part, line) adds a quarter of the nodes, the four partial flows meet
+    // in LDS and are added in part order — 4x the loads in flight of one thread per line walking all N nodes
+    const int LB = v.L > 0 ? (v.L + 63) / 64 : 1;
+    const int tid = threadIdx.x, t = blockIdx.x / LB, lb = blockIdx.x - t * LB;
     const int N = v.N, L = v.L, T = v.T;
     const size_t NT = (size_t)N * T, LT = (size_t)L * T;
     const double *cinj = v.cons, *cU = v.cons + NT, *cK = cU + LT;
@@ -710,12 +714,12 @@ __global__ __launch_bounds__(256) void k_dual_t(DevView v)
     for (int n = tid; n < N; n += 256) {
         const double x = cinj[n + (size_t)N * t] - v.demand[n + (size_t)N * t];
         q[n] = x;
-        v.inj[n + (size_t)N * t] = x;                                      // results.jl:58-100
+        if (lb == 0) v.inj[n + (size_t)N * t] = x;                        // results.jl:58-100
         part += x;
     }
     const double sum = block_sum256(part, red);                              // (barriers inside: q[] is complete)
     double rl = 0.0, rm = 0.0, rr = 0.0;
-    if (tid == 0) {
+    if (tid == 0 && lb == 0) {
         if (UPDATE) v.s_used[t] = v.s[t];
         v.s[t] = sum;
         if (UPDATE) {
@@ -725,40 +729,43 @@ __global__ __launch_bounds__(256) void k_dual_t(DevView v)
             rl = fabs(ln - lo);
         }
     }
-    int anyNeed = 0;
-    for (int l = tid; l < L; l += 256) {
+    {
+        const int pr = tid >> 6, ll = tid & 63, l = lb * 64 + ll;
+        const int Nc = (((N + 3) / 4) + 7) & ~7, nbeg = pr * Nc, nend = min(N, nbeg + Nc);
         double f = 0.0;
-        for (int n0 = 0; n0 < N; n0 += 8) {                                  // eight rows of ptdf in flight
-            double h[8];
+        if (l < L)
+            for (int n0 = nbeg; n0 < nend; n0 += 8) {                        // eight rows of ptdf in flight
+                double h[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) h[u] = n0 + u < N ? v.ptdf[l + (size_t)L * (n0 + u)] : 0.0;
+                for (int u = 0; u < 8; ++u) h[u] = n0 + u < nend ? v.ptdf[l + (size_t)L * (n0 + u)] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) f += h[u] * (n0 + u < N ? q[n0 + u] : 0.0);
-        }
-        const size_t i = l + (size_t)L * t;
-        if (UPDATE) { v.flow_used[i] = v.flow[i]; v.avgU_used[i] = v.avgU[i]; v.avgK_used[i] = v.avgK[i]; }
-        v.flow[i] = f;                                                       // results.jl:114
-        if (UPDATE) {
-            const double aU = v.invA * cU[i], aK = v.invA * cK[i];          // results.jl:108-112
-            v.avgU[i] = aU;
-            v.avgK[i] = aK;
-            const double mo = v.mu[i], ro = v.rho[i], F = v.fmax[l];
-            const double mn = (mo + v.gamma * (f + aU - F)) * (aU <= v.mask_thr ? 1.0 : 0.0);   // update_duals.jl:18-25
-            const double rn = (ro + v.gamma * (aK - f - F)) * (aK <= v.mask_thr ? 1.0 : 0.0);   // :30-37
-            v.mu_used[i] = mo; v.rho_used[i] = ro;
-            v.mu[i] = mn; v.rho[i] = rn;
-            rm = fmax(rm, fabs(mn - mo));
-            rr = fmax(rr, fabs(rn - ro));
-        }
-        {   // what the next slack sums of (l,t) will need (k_slack / k_reduce)
+                for (int u = 0; u < 8; ++u) f += h[u] * (n0 + u < nend ? q[n0 + u] : 0.0);
+            }
+        __syncthreads();
+        red[tid] = f;
+        __syncthreads();
+        if (pr == 0 && l < L) {
+            f = ((red[ll] + red[64 + ll]) + red[128 + ll]) + red[192 + ll];
+            const size_t i = l + (size_t)L * t;
+            if (UPDATE) { v.flow_used[i] = v.flow[i]; v.avgU_used[i] = v.avgU[i]; v.avgK_used[i] = v.avgK[i]; }
+            v.flow[i] = f;                                                       // results.jl:114
+            if (UPDATE) {
+                const double aU = v.invA * cU[i], aK = v.invA * cK[i];          // results.jl:108-112
+                v.avgU[i] = aU;
+                v.avgK[i] = aK;
+                const double mo = v.mu[i], ro = v.rho[i], F = v.fmax[l];
+                const double mn = (mo + v.gamma * (f + aU - F)) * (aU <= v.mask_thr ? 1.0 : 0.0);   // update_duals.jl:18-25
+                const double rn = (ro + v.gamma * (aK - f - F)) * (aK <= v.mask_thr ? 1.0 : 0.0);   // :30-37
+                v.mu_used[i] = mo; v.rho_used[i] = ro;
+                v.mu[i] = mn; v.rho[i] = rn;
+                rm = fabs(mn - mo);
+                rr = fabs(rn - ro);
+            }
+            // what the next slack sums of (l,t) will need (k_slack / k_reduce; the price kernel ORs them per timestep)
             const double w2 = 2.0 * v.w_flow, inv = 1.0 / (w2 + v.gamma);
-            const int need = slack_needs_cases(v.gamma, w2, inv, f, v.fmax[l], v.avgU[i], v.avgK[i], v.line_reach[l]) ? 1 : 0;
-            v.walk_flag[i] = need;
-            anyNeed |= need;
+            v.walk_flag[i] = slack_needs_cases(v.gamma, w2, inv, f, v.fmax[l], v.avgU[i], v.avgK[i], v.line_reach[l]) ? 1 : 0;
         }
     }
-    anyNeed = __syncthreads_or(anyNeed);
-    if (tid == 0 && L > 0) v.walk_any[t] = anyNeed ? 1 : 0;
     if (UPDATE) {
         // block max (order independent), then one atomic per block and residual
         __syncthreads();
@@ -774,7 +781,7 @@ __global__ __launch_bounds__(256) void k_dual_t(DevView v)
             if (rl > 0.0) atomic_max_pos(&v.st->resbits[0], rl);
             if (bm > 0.0) atomic_max_pos(&v.st->resbits[1], bm);
             if (red[0] > 0.0) atomic_max_pos(&v.st->resbits[2], red[0]);
-            if (t == 0) v.st->total_cost = v.cons[NT + 2 * LT];
+            if (t == 0 && lb == 0) v.st->total_cost = v.cons[NT + 2 * LT];
         }
     }
 }
@@ -782,30 +789,79 @@ __global__ __launch_bounds__(256) void k_dual_t(DevView v)
 template <bool UPDATE>
 __global__ __launch_bounds__(256) void k_price_t(DevView v)
 {
-    extern __shared__ double d[];            // L
+    extern __shared__ double d[];            // L: (mu - rho)[., t] | L: G[., t] | L: S[., t]
     const int tid = threadIdx.x, t = blockIdx.x;
     const int N = v.N, L = v.L;
+    double *Gl = d + L, *Sl = d + 2 * L;
+    // A timestep on which no line has a switch point within any node's reach (walk_any[t] == 0: the settled state) has
+    // EMPTY breakpoint tables: every line's slacks are in one regime for every move an agent can make, Psi_{n,t} is linear
+    // inside the node's window, Psi(0) = price + gamma s + sum_l h G_l and its slope = gamma + sum_l h^2 S_l with
+    //   G_l = w2 ((f + U0 - F) - (K0 - f - F)),  S_l = w2 (2 - (U on + K on) w2 / (w2 + gamma))
+    // — two more dot products along the loop that forms the price; k_tables then skips the timestep altogether.
+    int anyNeed = 0;
+    for (int l = tid; l < L; l += 256) anyNeed |= v.walk_flag[l + (size_t)L * t];
+    anyNeed = __syncthreads_or(anyNeed);
+    if (tid == 0 && L > 0) v.walk_any[t] = anyNeed ? 1 : 0;
+    const bool lin = L > 0 && !anyNeed;
+    const double w2 = 2.0 * v.w_flow, g = v.gamma, inv = 1.0 / (w2 + g);
     int nz = 0;
     for (int l = tid; l < L; l += 256) {
-        const double x = v.mu[l + (size_t)L * t] - v.rho[l + (size_t)L * t];
+        const size_t i = l + (size_t)L * t;
+        const double x = v.mu[i] - v.rho[i];
         d[l] = x;
         nz |= x != 0.0;
+        if (lin) {
+            const double f = v.flow[i], F = v.fmax[l];
+            const double U0 = dmax0((g * v.avgU[i] - w2 * (f - F)) * inv), K0 = dmax0((g * v.avgK[i] + w2 * (f + F)) * inv);
+            Gl[l] = w2 * ((f + U0 - F) - (K0 - f - F));
+            Sl[l] = w2 * (2.0 - ((U0 > 0.0 ? 1.0 : 0.0) + (K0 > 0.0 ? 1.0 : 0.0)) * w2 * inv);
+        }
     }
     nz = __syncthreads_or(nz);
     // recomputed even after a halt: the duals are frozen then, so the values are identical
-    const double lam = v.lam[t];
-    for (int n = tid; n < N; n += 256) {
-        double p = lam;
-        if (nz)
-            for (int l0 = 0; l0 < L; l0 += 8) {                              // ptdfT[n + N l]: coalesced over the nodes
+    const double lam = v.lam[t], gs = g * v.s[t];
+    // thread (part, n): the lines are cut into P contiguous parts so that a block of N < 256 nodes still fills its
+    // 256 threads; partial dot products meet in LDS and are added in part order (fixed: deterministic)
+    __shared__ double redp[3][256];
+    const int NP = N <= 256 ? ((N + 31) & ~31) : 256, P = 256 / NP;
+    const int part = tid / NP, nn = tid - part * NP;
+    const int Lc = (((L + P - 1) / P) + 7) & ~7, lbeg = part * Lc, lend = min(L, lbeg + Lc);
+    for (int nb = 0; nb < N; nb += NP) {
+        const int n = nb + nn;
+        double p = 0.0, ps = 0.0, sl = 0.0;
+        if (n < N && part < P && (nz || lin))
+            for (int l0 = lbeg; l0 < lend; l0 += 8) {                        // ptdfT[n + N l]: coalesced over the nodes
                 double h[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) h[u] = l0 + u < L ? v.ptdfT[n + (size_t)N * (l0 + u)] : 0.0;
+                for (int u = 0; u < 8; ++u) h[u] = l0 + u < lend ? v.ptdfT[n + (size_t)N * (l0 + u)] : 0.0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) p += h[u] * (l0 + u < L ? d[l0 + u] : 0.0);
+                for (int u = 0; u < 8; ++u) p += h[u] * (l0 + u < lend ? d[l0 + u] : 0.0);
+                if (lin) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (l0 + u < lend) { ps += h[u] * Gl[l0 + u]; sl += h[u] * h[u] * Sl[l0 + u]; }
+                }
             }
-        v.price[n + (size_t)N * t] = p;
+        if (P > 1) {
+            __syncthreads();
+            redp[0][tid] = p; redp[1][tid] = ps; redp[2][tid] = sl;
+            __syncthreads();
+            if (part == 0) {
+                for (int q = 1; q < P; ++q) { p += redp[0][q * NP + nn]; ps += redp[1][q * NP + nn]; sl += redp[2][q * NP + nn]; }
+            }
+        }
+        if (n < N && part == 0) {
+            const size_t at = n + (size_t)N * t;
+            p += lam;
+            v.price[at] = p;
+            if (lin) {
+                v.tb_m[at] = 0;
+                v.tb_psi0[at] = (p + gs) + ps;
+                v.tb_slope[at * (v.M2 + 1)] = g + sl;
+            }
+        }
     }
+    if (L > 0 && tid == 0) v.tab_skip[t] = lin ? 1 : 0;
     if (UPDATE && t == 0 && tid == 0) {
         Status *st = v.st;
         if (st->halt) return;
@@ -908,9 +964,9 @@ void launch_dual(const DevView &v, hipStream_t s)
         hipLaunchKernelGGL(k_dual_price_small<true>, dim3(1), dim3(256), 0, s, v);
         return;
     }
-    if ((size_t)std::max(v.N, v.L) * sizeof(double) <= 48 * 1024) {
-        hipLaunchKernelGGL(k_dual_t<true>, dim3(v.T), dim3(256), (size_t)v.N * sizeof(double), s, v);
-        hipLaunchKernelGGL(k_price_t<true>, dim3(v.T), dim3(256), (size_t)v.L * sizeof(double), s, v);
+    if ((size_t)std::max(v.N, 3 * v.L) * sizeof(double) <= 48 * 1024) {
+        hipLaunchKernelGGL(k_dual_t<true>, dim3(v.T * (v.L > 0 ? (v.L + 63) / 64 : 1)), dim3(256), (size_t)v.N * sizeof(double), s, v);
+        hipLaunchKernelGGL(k_price_t<true>, dim3(v.T), dim3(256), 3 * (size_t)v.L * sizeof(double), s, v);
         return;
     }
     if (v.L > 0) hipMemsetAsync(v.walk_any, 0, sizeof(int) * v.T, s);
@@ -957,9 +1013,9 @@ void launch_derive(const DevView &v, hipStream_t s, bool from_primal)
         hipLaunchKernelGGL(k_dual_price_small<false>, dim3(1), dim3(256), 0, s, v);
         return;
     }
-    if ((size_t)std::max(v.N, v.L) * sizeof(double) <= 48 * 1024) {
-        hipLaunchKernelGGL(k_dual_t<false>, dim3(v.T), dim3(256), (size_t)v.N * sizeof(double), s, v);
-        hipLaunchKernelGGL(k_price_t<false>, dim3(v.T), dim3(256), (size_t)v.L * sizeof(double), s, v);
+    if ((size_t)std::max(v.N, 3 * v.L) * sizeof(double) <= 48 * 1024) {
+        hipLaunchKernelGGL(k_dual_t<false>, dim3(v.T * (v.L > 0 ? (v.L + 63) / 64 : 1)), dim3(256), (size_t)v.N * sizeof(double), s, v);
+        hipLaunchKernelGGL(k_price_t<false>, dim3(v.T), dim3(256), 3 * (size_t)v.L * sizeof(double), s, v);
         return;
     }
     if (v.L > 0) hipMemsetAsync(v.walk_any, 0, sizeof(int) * v.T, s);

@@ -86,6 +86,23 @@ def aggregate_copper_plate(pp):
                     sto_node=np.zeros(sk.shape[0], dtype=np.int32), meta=dict(aggregated_from=(pp.G, pp.S)))
 
 
+def aggregate_by_node(pp):
+    """Network cases: units at the same node are interchangeable in the LP when their cost is the same and (storages)
+    their level/power ratio is the same — capacities add up, the optimum is unchanged. Turns the 100 000-agent
+    configuration on the 118-node network into ~7 400 units."""
+    gk = np.stack([pp.gen_node.astype(np.float64), pp.gen_mc], axis=1)
+    gu, ginv = np.unique(gk, axis=0, return_inverse=True)
+    gp = np.bincount(ginv.ravel(), weights=pp.gen_pmax, minlength=gu.shape[0])
+    ratio = pp.sto_emax / pp.sto_pmax
+    sk = np.stack([pp.sto_node.astype(np.float64), pp.sto_mc, ratio], axis=1)
+    su, sinv = np.unique(sk, axis=0, return_inverse=True)
+    sp = np.bincount(sinv.ravel(), weights=pp.sto_pmax, minlength=su.shape[0])
+    se = np.bincount(sinv.ravel(), weights=pp.sto_emax, minlength=su.shape[0])
+    return type(pp)(N=pp.N, L=pp.L, T=pp.T, demand=pp.demand, ptdf=pp.ptdf, f_max=pp.f_max, gen_mc=gu[:, 1], gen_pmax=gp,
+                    gen_node=gu[:, 0].astype(np.int32), sto_mc=su[:, 1], sto_pmax=sp, sto_emax=se,
+                    sto_node=su[:, 0].astype(np.int32), meta=dict(aggregated_from=(pp.G, pp.S)))
+
+
 def solve_central_nodal(pp):
     """Same LP with explicit nodal injections I[n,t] = sum of the node's units - demand: the flow limits then have
     N nonzeros per row instead of one per unit, which is what makes the 118-node / 12 500-agent share solvable."""

@@ -372,6 +372,63 @@ def test_hip_network_share_reaches_central_optimum(hip_api):
     assert e.solver_failures() == 0
 
 
+def test_hip_config3_full_size(hip_api):
+    """BASELINE configs[3] at its real size on ONE GPU: synthetic 118-node / 186-line network, 100 000 agents x 168.
+    Size-independent properties of one iteration (closed-form slack sums against an agent-by-agent evaluation, flows,
+    dual step, storage certificates), then the run to the 1e-3 residual and its cost against the central LP optimum
+    (tests/golden/make_config3_optimum.py: units aggregated per node and cost, exact for the LP)."""
+    from conftest import load_golden
+    pp = synth.baseline_config(3)
+    opt = load_golden("synthetic_optima")["config3"]
+    assert (opt["G"], opt["S"], opt["T"], opt["N"], opt["L"]) == (pp.G, pp.S, pp.T, pp.N, pp.L) == (90910, 9090, 168, 118, 186)
+    A = pp.G + pp.S
+    g, wf = 1.0 / A, 0.3 / A
+    e = make_engine(hip_api, pp, gamma=g, w_flow=wf, max_iters=5000)
+    e.iterate(20)
+    before = state_of(e)
+    lam0, mu0, rho0 = e.get_duals()
+    e.iterate(1)
+    after = state_of(e)
+    # consensus sums from what the agents report: injection, flows = ptdf . injection
+    inj = -pp.demand.copy()
+    np.add.at(inj, pp.gen_node, after["P"])
+    np.add.at(inj, pp.sto_node, after["D"] - after["C"])
+    mag = np.abs(pp.demand).max() + 1.0
+    assert np.abs(after["inj"] - inj).max() <= 1e-10 * mag * 100
+    assert np.abs(after["flow"] - pp.ptdf @ after["inj"]).max() <= 1e-9 * mag
+    # mean slacks: U_a = max(0, (g a - w2 (f + h d_a - F)) / (w2 + g)) summed agent by agent (SURVEY.md 9.4)
+    w2 = 2 * wf
+    dG = after["P"] - before["P"]
+    dS = (after["D"] - after["C"]) - (before["D"] - before["C"])
+    sumU = np.zeros((pp.L, pp.T))
+    sumK = np.zeros((pp.L, pp.T))
+    for n in range(pp.N):
+        d = np.concatenate([dG[pp.gen_node == n], dS[pp.sto_node == n]], axis=0)          # (agents at n, T)
+        if d.shape[0] == 0:
+            continue
+        fl = before["flow"][None, :, :] + pp.ptdf[:, n][None, :, None] * d[:, None, :]      # (a, L, T)
+        sumU += np.maximum(0.0, (g * before["avg_U"][None] - w2 * (fl - pp.f_max[None, :, None])) / (w2 + g)).sum(axis=0)
+        sumK += np.maximum(0.0, (g * before["avg_K"][None] + w2 * (fl + pp.f_max[None, :, None])) / (w2 + g)).sum(axis=0)
+    assert np.abs(after["avg_U"] - sumU / A).max() <= 1e-9 * max(1.0, np.abs(sumU / A).max())
+    assert np.abs(after["avg_K"] - sumK / A).max() <= 1e-9 * max(1.0, np.abs(sumK / A).max())
+    # dual step (update_duals.jl:1-39) from the reported consensus state
+    assert np.abs(after["lam"] - (lam0 + g * after["inj"].sum(axis=0))).max() <= 1e-9 * max(1.0, np.abs(after["lam"]).max())
+    mu1 = (mu0 + g * (after["flow"] + after["avg_U"] - pp.f_max[:, None])) * (after["avg_U"] <= 1e-2)
+    rho1 = (rho0 + g * (after["avg_K"] - after["flow"] - pp.f_max[:, None])) * (after["avg_K"] <= 1e-2)
+    assert np.abs(after["mu"] - mu1).max() <= 1e-12 + 1e-9 * np.abs(mu1).max() and np.abs(after["rho"] - rho1).max() <= 1e-12 + 1e-9 * np.abs(rho1).max()
+    # storages: bounds and level recursion
+    D, C, E = after["D"], after["C"], after["E"]
+    assert D.min() >= 0 and C.min() >= 0 and (D - pp.sto_pmax[:, None]).max() <= 0 and (C - pp.sto_pmax[:, None]).max() <= 0
+    assert E.min() >= -1e-9 and (E - pp.sto_emax[:, None]).max() <= 1e-9 and np.abs(np.cumsum(C - D, axis=1) - E).max() < 1e-9
+    # the run to the stop test, and its optimum
+    done, conv = e.iterate(5000)
+    assert conv and done < 1500
+    inj, aU, aK, flow, cost = e.get_consensus()
+    assert abs(cost - opt["objective"]) / opt["objective"] < 1e-3
+    assert (np.abs(flow) - pp.f_max[:, None]).max() <= 1e-6 * pp.f_max.max()
+    assert e.solver_failures() == 0
+
+
 def test_hip_config1_reaches_central_optimum(hip_api):
     """BASELINE config 1 (1000 gens + 100 storages x 24): converges (gamma = 1/A) to the LP optimum."""
     pp = synth.baseline_config(1)
