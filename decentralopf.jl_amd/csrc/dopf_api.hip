@@ -243,9 +243,14 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
 
     if (q->stream) { c->main = (hipStream_t)q->stream; c->own_main = false; }
     else { HIPTRY(hipStreamCreateWithFlags(&c->main, hipStreamNonBlocking)); c->own_main = true; }
-    HIPTRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-    HIPTRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
-    HIPTRY(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
+    // the side stream exists only when it is used: HIP maps streams onto a few hardware queues (4 by default), and a
+    // process whose streams outnumber them pays barrier packets on every launch (measured: two contexts + PyTorch's
+    // own streams made a 118-node iteration 4x slower)
+    if (q->flags & DOPF_F_OVERLAP_AGENTS) {
+        HIPTRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        HIPTRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+        HIPTRY(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
+    }
 
     DevView &v = c->v;
     const int N = p->N, L = p->L, T = p->T, G = p->G, S = p->S;
@@ -491,7 +496,7 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
     HIPCHK(c, hipGetLastError());
     int rc = read_status(c);
     if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->side));
+    if (c->side) HIPCHK(c, hipStreamSynchronize(c->side));
     memset(out, 0, sizeof *out);
     auto ms = [&](hipEvent_t a, hipEvent_t b) { float f = 0.f; hipEventElapsedTime(&f, a, b); return (double)f; };
     for (int i = 0; i < n_iters; ++i) {

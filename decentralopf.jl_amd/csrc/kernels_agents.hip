@@ -1135,7 +1135,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
 
             // ---- B. segmented Newton, bracketed --------------------------------------------------------------
             DOPF_TOC(0)
-            double px[NCH], ps[NCH];
+            double px[NCH], ps[NCH], Dv[NCH], Cv[NCH];
             bool nconv = false, nfail = false;
             for (int itn = 0; itn < MAXN; ++itn) {
 #ifdef DOPF_STATS
@@ -1148,6 +1148,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
                     for (int c = 0; c < NCH; ++c) {
                         double dd = 0.0, cc = 0.0, s1 = 0.0;
                         if (tbase + c < T) eval(c, nuv[c], dd, cc, s1);
+                        Dv[c] = dd; Cv[c] = cc;            // (of the last evaluation: the certified values when the round passes)
                         if (STARTS(c)) { rx = 0.0; rs = 0.0; f = 1; }
                         rx += cc - dd; rs += s1;
                         px[c] = rx; ps[c] = rs;
@@ -1260,14 +1261,8 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
             DOPF_TOC(1)
             bool okk = true;
             int nkind[NCH];
-            double Dv[NCH], Cv[NCH];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                nkind[c] = kind[c];
-                double s1;
-                Dv[c] = 0.0; Cv[c] = 0.0;
-                if (tbase + c < T) eval(c, nuv[c], Dv[c], Cv[c], s1);       // (the values px was summed from)
-            }
+            for (int c = 0; c < NCH; ++c) nkind[c] = kind[c];
             // Copper plate: a segment whose steps ALL sit on a corner of their (D, C) box (charging or discharging at
             // full rate, or idle) does not move with its price: every price in the intersection of the steps' corner
             // intervals is a multiplier of that segment, not just the one Newton happened to stop at. With
@@ -1458,7 +1453,7 @@ __global__ __launch_bounds__(256) void k_sto_warm(DevView v)
 // Warm start and, in the same block, the cold scan for what it left over: one launch for the storages of the big
 // copper-plate grids (the separate k_sto_update launch mostly found nothing to do).
 template <int LPS, int NCH, bool LINES>
-__global__ __launch_bounds__(256) void k_sto(DevView v)
+__global__ __launch_bounds__(256, 3) void k_sto(DevView v)
 {
     if (v.st->halt) return;
     const int left = sto_warm_body<LPS, NCH, LINES>(v, blockIdx.x);         // ends on a __syncthreads: its sto_fail
@@ -1473,7 +1468,7 @@ __global__ __launch_bounds__(256) void k_sto(DevView v)
 // The launch runs at the storage code's 3 waves/SIMD, which starves the streaming generator blocks once the
 // grid is large, so dopf_create only fuses grids whose storage blocks are all resident from the start.
 template <int LPS, int NCH, bool SKIP>
-__global__ __launch_bounds__(256) void k_agents(DevView v)
+__global__ __launch_bounds__(256, 3) void k_agents(DevView v)
 {
     if (v.st->halt) return;
     const int nS = v.nStoItems;

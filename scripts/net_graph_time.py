@@ -20,3 +20,7 @@ for w in range(nw):
     t0 = time.perf_counter(); e.iterate(wlen); dt = time.perf_counter() - t0
     it += wlen
     print(f"its {it - wlen + 1}..{it}: {1e6 * dt / wlen:.1f} us/iteration", flush=True)
+for pause in (0.0, 0.2, 1.0):
+    time.sleep(pause)
+    t0 = time.perf_counter(); e.iterate(200); dt = time.perf_counter() - t0
+    print(f"after a {pause:.1f} s pause: 200 its at {1e6 * dt / 200:.1f} us/iteration", flush=True)
