@@ -303,6 +303,7 @@ static void qp_add_sq(qp_obj *o, double coef, int k, const int *idx, const doubl
 
 struct oracle_ctx {
     int N, L, T, G, S, mode, nthreads;
+    int bisect_only;        /* ORACLE_BISECT=1: plain bisection in the exact storage solve (cross-check of the regula falsi) */
     double *demand, *ptdf, *fmax, *gen_mc, *gen_pmax, *sto_mc, *sto_pmax, *sto_emax;
     int *gen_node, *sto_node;
     dopf_params q;
@@ -356,6 +357,7 @@ int oracle_create(oracle_ctx **out, const dopf_problem *p, const dopf_params *q,
     oracle_ctx *c = (oracle_ctx *)calloc(1, sizeof *c);
     if (!c) return DOPF_E_NOMEM;
     c->N = p->N; c->L = p->L; c->T = p->T; c->G = p->G; c->S = p->S; c->mode = mode; c->nthreads = 1;
+    { const char *e = getenv("ORACLE_BISECT"); c->bisect_only = (e && e[0] == '1') ? 1 : 0; }
     c->q = *q;
     c->A_global = q->n_agents_global > 0 ? q->n_agents_global : p->G + p->S;
     const size_t NT = (size_t)p->N * p->T, LT = (size_t)p->L * p->T;
@@ -720,13 +722,38 @@ static int exact_storage(const oracle_ctx *c, int s, double *Dn, double *Cn, dou
         if (low) { do { b = nu + step; step *= 2; sto_scan(c, st, v, emax, b, Dv, Cv, Fv, Sv, tol); } while (Sv[v] < target && ++guard < 1100); }
         else     { do { a = nu - step; step *= 2; sto_scan(c, st, v, emax, a, Dv, Cv, Fv, Sv, tol); } while (Sv[v] > target && ++guard < 1100); }
         if (guard >= 1100) { rc = -1; break; }
-        for (int it = 0; it < 300; ++it) {
-            double mid = 0.5 * (a + b);
-            if (!(mid > a && mid < b)) break;
-            sto_scan(c, st, v, emax, mid, Dv, Cv, Fv, Sv, tol);
-            if (Sv[v] < target) a = mid; else b = mid;
+        /* S_v(a) <= target <= S_v(b). Bracketed regula falsi (Illinois): S_v is piecewise linear, so the secant lands on
+         * the root's piece after a few steps; every third step, and whenever the secant point is not strictly inside, the
+         * bracket is halved. ORACLE_BISECT=1 (environment) keeps the plain bisection of round 1 as a cross-check. */
+        int found = 0;
+        if (!c->bisect_only) {
+            double fa, fb;
+            sto_scan(c, st, v, emax, a, Dv, Cv, Fv, Sv, tol); fa = Sv[v] - target;
+            sto_scan(c, st, v, emax, b, Dv, Cv, Fv, Sv, tol); fb = Sv[v] - target;
+            const double rtol = 1e-13 * (1.0 + emax);
+            if (fabs(fa) <= rtol) { nu = a; found = 1; }
+            else if (fabs(fb) <= rtol) { nu = b; found = 1; }
+            int side = 0;
+            for (int it = 0; it < 200 && !found; ++it) {
+                double x = (fb != fa) ? b - fb * (b - a) / (fb - fa) : 0.5 * (a + b);
+                if (it % 3 == 2 || !(x > a && x < b)) x = 0.5 * (a + b);
+                if (!(x > a && x < b)) break;                       /* adjacent doubles */
+                sto_scan(c, st, v, emax, x, Dv, Cv, Fv, Sv, tol);
+                const double fx = Sv[v] - target;
+                if (fabs(fx) <= rtol) { nu = x; found = 1; break; }
+                if (fx < 0.0) { a = x; fa = fx; if (side == -1) fb *= 0.5; side = -1; }
+                else          { b = x; fb = fx; if (side == 1) fa *= 0.5; side = 1; }
+            }
         }
-        nu = low ? b : a;
+        if (!found) {
+            for (int it = 0; it < 300; ++it) {
+                double mid = 0.5 * (a + b);
+                if (!(mid > a && mid < b)) break;
+                sto_scan(c, st, v, emax, mid, Dv, Cv, Fv, Sv, tol);
+                if (Sv[v] < target) a = mid; else b = mid;
+            }
+            nu = low ? b : a;
+        }
         sto_scan(c, st, v, emax, nu, Dv, Cv, Fv, Sv, tol);
         Dn[v] = Dv[v]; Cn[v] = Cv[v];
         k = v - 1;
