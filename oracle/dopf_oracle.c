@@ -730,7 +730,7 @@ static int exact_storage(const oracle_ctx *c, int s, double *Dn, double *Cn, dou
             double fa, fb;
             sto_scan(c, st, v, emax, a, Dv, Cv, Fv, Sv, tol); fa = Sv[v] - target;
             sto_scan(c, st, v, emax, b, Dv, Cv, Fv, Sv, tol); fb = Sv[v] - target;
-            const double rtol = 1e-13 * (1.0 + emax);
+            const double rtol = 1e-12 * (1.0 + emax);      /* the tolerance of the HIP kernels' root searches */
             if (fabs(fa) <= rtol) { nu = a; found = 1; }
             else if (fabs(fb) <= rtol) { nu = b; found = 1; }
             int side = 0;
