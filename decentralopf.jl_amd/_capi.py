@@ -56,6 +56,7 @@ F_NO_ROW_SKIP = 8
 F_NO_FUSE = 16
 F_COMM_HOST = 64
 F_DEBUG_ROOT_CAP = 128
+F_KEEP_DELTAS = 256
 COMM_ID_BYTES = 128
 
 

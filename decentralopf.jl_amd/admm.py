@@ -118,6 +118,8 @@ class ADMM:
             self.node_to_units.setdefault(id(u.node), []).append(u)
         self.record = record
         self.record_slacks = record_slacks        # also fetch every unit's U, K and PenaltyTerm (diagnostics, HIP backend)
+        if record_slacks:
+            params["flags"] = int(params.get("flags", 0)) | _capi.F_KEEP_DELTAS
         self.params = _capi.default_params(gamma=self.gamma, max_iters=max_iters, **params)
         self.engine = _capi.Engine(backend if backend is not None else _capi.hip_api(),
                                    params=self.params, mode=backend_mode, **p.engine_kwargs())

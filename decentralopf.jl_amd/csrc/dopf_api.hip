@@ -258,7 +258,8 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     v.gamma = q->gamma; v.w_flow = q->w_flow; v.w_prox = q->w_prox; v.eps = q->eps; v.mask_thr = q->mask_thr;
     v.max_iters = q->max_iters;
     v.rootCap = (q->flags & DOPF_F_DEBUG_ROOT_CAP) ? 2 : 80;
-    v.dbg = q->flags >> 8;
+    v.dbg = q->flags >> 12;
+    v.keepDeltas = (q->flags & DOPF_F_KEEP_DELTAS) ? 1 : 0;
     const int A = q->n_agents_global > 0 ? q->n_agents_global : G + S;
     v.invA = A > 0 ? 1.0 / (double)A : 0.0;
     v.use_warm = (S > 0 && lc.stoNCH <= 3 && !(q->flags & DOPF_F_NO_WARM_START)) ? 1 : 0;
@@ -376,6 +377,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     TRY(dev_alloc(c, &v.part_ginj, (size_t)v.nGenItems * T)); TRY(dev_alloc(c, &v.part_gcost, v.nGenItems));
     TRY(dev_alloc(c, &v.part_sinj, (size_t)v.nStoItems * T)); TRY(dev_alloc(c, &v.part_scost, v.nStoItems));
     TRY(dev_alloc(c, &v.part_sinj_w, (size_t)v.nStoItems * T)); TRY(dev_alloc(c, &v.part_scost_w, v.nStoItems));
+    if (L > 0) { TRY(dev_alloc(c, &v.prev_ginj, (size_t)v.nGenItems * T)); TRY(dev_alloc(c, &v.prev_sinj, (size_t)v.nStoItems * T)); }
     TRY(dev_alloc(c, &v.nu_prev, (size_t)S * T)); TRY(dev_alloc(c, &v.nu_valid, S)); TRY(dev_alloc(c, &v.sto_fail, S));
     TRY(dev_alloc(c, &v.item_fail, v.nStoItems));
     TRY(dev_alloc(c, &v.part2, (size_t)N * v.reduceRB * T)); TRY(dev_alloc(c, &v.part2_cost, v.reduceRB));
@@ -756,6 +758,8 @@ static int agent_result(dopf_ctx *c, int32_t agent, const double *delta_in, doub
         if (pen) return fail(c, DOPF_E_UNSUPPORTED, "copper plate: the agent's injection change is not kept on the device (pass it in)");
         return DOPF_OK;         // no lines: U and K are empty
     }
+    if (!delta_in && !v.keepDeltas)
+        return fail(c, DOPF_E_UNSUPPORTED, "the agents' injection changes are kept on the device only with DOPF_F_KEEP_DELTAS (or pass the change in)");
     DeviceGuard guard(c->device);
     const bool is_gen = agent < G;
     const std::vector<int> &perm = is_gen ? c->gen_perm : c->sto_perm;

@@ -54,6 +54,7 @@ struct DevView {
     int fuseAgents;                 // copper plate, even T: generators + storages in one launch (k_agents, 256-thread blocks)
     int use_warm;                   // storage warm-start kernel runs first; the scan kernel serves its failures
     int max_iters;
+    int keepDeltas;                 // DOPF_F_KEEP_DELTAS: dltG / dltS are written for every timestep (diagnostic getters)
     int dbg;                        // experiments: flags >> 8
     int rootCap;                    // iteration cap of the scan kernel's root search (80; 2 with DOPF_F_DEBUG_ROOT_CAP)
     double gamma, w_flow, w_prox, eps, mask_thr, invA;
@@ -83,7 +84,9 @@ struct DevView {
     double *nu_prev;                                // [t + T*s] price of stored energy of the last solve
     int *nu_valid, *sto_fail, *item_fail;           // [s], [s], [item] (= storages of the item the warm start left over)
     double *part_U, *part_K;                        // [(n + N*t)*L + l]: only the entries k_slack had to walk agent by agent
-    double *node_dsum;                              // [n + N*t] sum of the node's agents' injection changes (L > 0)
+    double *node_dsum;                              // [n + N*t] change of the node's injection in this iteration (L > 0)
+    double *prev_ginj, *prev_sinj;                  // [item*T + t] the items' injection sums of the previous iteration (L > 0): the change of a
+                                                    // node's injection, which the closed-form slack sums need, is new - previous over its items
     const double *line_reach;                       // [l] max over nodes of |kap| W_n: beyond it no agent of any node can flip the line's slack
     int *tab_skip;                                  // [t] the price kernel has written the (empty) tables of timestep t
     int *walk_flag, *walk_any;                      // [l + L*t], [t]: the slack sums of (l,t) need the per-node cases (set by the dual step)

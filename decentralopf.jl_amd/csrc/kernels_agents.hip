@@ -65,6 +65,7 @@ __global__ __launch_bounds__(512) void k_gen_update(DevView v)
                 const double *slope = v.tb_slope + at * (v.M2 + 1);
                 const double psi0 = v.tb_psi0[at];
                 const double slope0 = slope[0];
+                const bool keepd = v.keepDeltas || v.walk_any[t];      // the change is needed agent by agent only for walked slack sums
                 for (int g0 = it.a0 + r; g0 < it.a1; g0 += 4 * R) {          // four agents' rows in flight per lane
                     double mc[4], pm[4], p0[4];
 #pragma unroll
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(512) void k_gen_update(DevView v)
                         }
                         const double pn = clampd(p0[u] + dl, 0.0, pm[u]);
                         v.P[e] = pn;
-                        v.dltG[e] = pn - p0[u];
+                        if (keepd) v.dltG[e] = pn - p0[u];
                         acc += pn;
                         cost += mc[u] * pn;
                     }
@@ -768,7 +769,7 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
                 v.D[e] = Dn[c];
                 v.C[e] = Cn[c];
                 v.E[e] = ev;
-                if (LINES) v.dltS[e] = (Dn[c] - Cn[c]) - (D0[c] - C0[c]);
+                if (LINES && (v.keepDeltas || v.walk_any[tbase + c])) v.dltS[e] = (Dn[c] - Cn[c]) - (D0[c] - C0[c]);
                 v.nu_prev[e] = nuf[c];
                 accQ[c] += Dn[c] - Cn[c];
                 accCost += ag.mc * (Dn[c] + Cn[c]);
@@ -1378,7 +1379,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
                         v.C[e] = Cv[c];
                         v.E[e] = bs[c] + px[c];
                         v.nu_prev[e] = nuc[c];
-                        if (LINES) v.dltS[e] = (Dv[c] - Cv[c]) - (A0[c] - B0[c]);
+                        if (LINES && (v.keepDeltas || v.walk_any[t])) v.dltS[e] = (Dv[c] - Cv[c]) - (A0[c] - B0[c]);
                         accQ[c] += Dv[c] - Cv[c];
                         accCost += mc * (Dv[c] + Cv[c]);
                     }

@@ -233,8 +233,6 @@ __global__ __launch_bounds__(256) void k_slack(DevView v, const int cap)
 {
     if (v.st->halt) return;
     constexpr int TS = 32;                   // timesteps per block: the agents' changes are read along t (coalesced)
-    __shared__ double red[256];
-    __shared__ double sumD[TS];
     extern __shared__ double dtile[];        // [a * 33 + tt] for the node's first `cap` agents (padded rows)
     const int tid = threadIdx.x;
     const int N = v.N, L = v.L, T = v.T;
@@ -245,44 +243,57 @@ __global__ __launch_bounds__(256) void k_slack(DevView v, const int cap)
     const int na = ng + ns;
     const double w2 = 2.0 * v.w_flow, g = v.gamma, inv = 1.0 / (w2 + g);
     const double W = v.node_win[n];
-    // sum of the node's injection changes per timestep: a line whose slack stays active (or inactive) for EVERY
-    // change an agent of this node can make, |d| <= W, needs only this sum — the usual case; only (line, timestep)
-    // pairs with a switch point inside the window walk the agents one by one
+    const int nt = min(TS, T - t0), np = L * nt;
+    {   // the change of the node's injection in this iteration = new minus previous sum of its items' partials (read along
+        // t: coalesced); the new sums become "previous" for the next iteration — this block owns these (item, t) entries
+        const int r = tid >> 5, tt = tid & 31, t = t0 + tt;
+        __shared__ double redn[256];
+        double sd = 0.0;
+        if (t < T) {
+            const int g0 = v.node_gitem_beg[n], g1 = v.node_gitem_beg[n + 1], s0 = v.node_sitem_beg[n], s1 = v.node_sitem_beg[n + 1];
+            for (int j = g0 + r; j < g1; j += 8) {
+                const double now = v.part_ginj[(size_t)j * T + t];
+                sd += now - v.prev_ginj[(size_t)j * T + t];
+                v.prev_ginj[(size_t)j * T + t] = now;
+            }
+            for (int j = s0 + r; j < s1; j += 8) {
+                const double now = v.part_sinj[(size_t)j * T + t] + v.part_sinj_w[(size_t)j * T + t];
+                sd += now - v.prev_sinj[(size_t)j * T + t];
+                v.prev_sinj[(size_t)j * T + t] = now;
+            }
+        }
+        redn[tid] = sd;
+        __syncthreads();
+        if (r == 0 && t < T) {
+            double sum = 0.0;
+            for (int q = 0; q < 8; ++q) sum += redn[q * 32 + tt];
+            v.node_dsum[n + (size_t)N * t] = sum;
+        }
+    }
+    {   // usually no (line, timestep) of this chunk has a switch point within anybody's reach: k_reduce takes the closed forms
+        int any = 0;
+        if (tid < nt) any = v.walk_any[t0 + tid];
+        if (!__syncthreads_or(any)) return;
+    }
+    // the node's injection changes of the chunk's timesteps, staged in LDS for the walks (read along t: coalesced)
     {
         const int r = tid >> 5, tt = tid & 31, t = t0 + tt;
-        double sd = 0.0;
         if (t < T)
-            for (int a0 = r; a0 < na; a0 += 32) {         // four rows in flight per lane
+            for (int a0 = r; a0 < na && a0 < cap; a0 += 32) {         // four rows in flight per lane
                 double d[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int a = a0 + 8 * u;
                     const int aa = a < na ? a : r;            // (a valid row; value dropped below)
-                    const double x = aa < ng ? v.dltG[(size_t)(gb + aa) * T + t] : v.dltS[(size_t)(sb + aa - ng) * T + t];
-                    d[u] = a < na ? x : 0.0;
+                    d[u] = aa < ng ? v.dltG[(size_t)(gb + aa) * T + t] : v.dltS[(size_t)(sb + aa - ng) * T + t];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int a = a0 + 8 * u;
                     if (a < na && a < cap) dtile[a * 33 + tt] = d[u];
-                    sd += d[u];
                 }
             }
-        red[tid] = sd;
         __syncthreads();
-        if (r == 0) {
-            double sum = 0.0;
-            for (int q = 0; q < 8; ++q) sum += red[q * 32 + tt];
-            sumD[tt] = sum;
-            if (t < T) v.node_dsum[n + (size_t)N * t] = sum;
-        }
-        __syncthreads();
-    }
-    const int nt = min(TS, T - t0), np = L * nt;
-    {   // usually no (line, timestep) of this chunk has a switch point within anybody's reach: the node sums were all
-        int any = 0;
-        if (tid < nt) any = v.walk_any[t0 + tid];
-        if (!__syncthreads_or(any)) return;
     }
     for (int p0 = tid; p0 < np; p0 += 4 * 256) {          // pairs (l fastest: coalesced), four per lane in flight
         double h[4], f[4], F[4], cu[4], ck[4];
@@ -439,9 +450,10 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
             if (tid == 0) v.reduce_ticket[n * TC + tcx] = 0;       // ready for the next iteration
         }
     } else {
-        // slack sums: one block per (timestep, U|K); the node sums of the timestep and the nodes' constants are staged
-        // in LDS, a thread owns a line and walks the nodes in a fixed order (eight ptdf loads in flight)
-        extern __shared__ double nsh[];               // [N] node sums of timestep t | [N] window | [N] agents at the node
+        // slack sums: one block per timestep (U, then K); the change of every node's injection in this iteration — new minus
+        // previous sum of its items' partials — and the nodes' constants are staged in LDS, a thread owns a line and walks
+        // the nodes in a fixed order (eight ptdf loads in flight)
+        extern __shared__ double nsh[];               // [N] node changes of timestep t | [N] window | [N] agents at the node
         double *sdL = nsh, *winL = nsh + N, *naL = nsh + 2 * N;
         const int b2 = blockIdx.x - N * RB * TC, t = b2 >> 1, which = b2 & 1;
         if (v.dbg & 1) return;
@@ -451,6 +463,7 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
             naL[n] = (double)((v.node_gen_beg[n + 1] - v.node_gen_beg[n]) + (v.node_sto_beg[n + 1] - v.node_sto_beg[n]));
         }
         __syncthreads();
+        {
         const double *src = which ? v.part_K : v.part_U;
         const double w2 = 2.0 * v.w_flow, g = v.gamma, inv = 1.0 / (w2 + g);
         for (int l = tid; l < L; l += 256) {
@@ -533,6 +546,22 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
             }
             v.cons[(size_t)N * T + (size_t)which * L * T + rem] = sum;
         }
+        }
+    }
+}
+
+// set_state support: the items' injection sums of the state handed in (what the next iteration's node changes refer to)
+__global__ __launch_bounds__(256) void k_derive_items(DevView v)
+{
+    const int T = v.T, nG = v.nGenItems;
+    const bool gen = (int)blockIdx.x < nG;
+    const Item it = gen ? v.gen_items[blockIdx.x] : v.sto_items[blockIdx.x - nG];
+    for (int t = threadIdx.x; t < T; t += 256) {
+        double sum = 0.0;
+        for (int a = it.a0; a < it.a1; ++a)
+            sum += gen ? v.P[(size_t)a * T + t] : v.D[(size_t)a * T + t] - v.C[(size_t)a * T + t];
+        if (gen) v.prev_ginj[(size_t)blockIdx.x * T + t] = sum;
+        else v.prev_sinj[(size_t)(blockIdx.x - nG) * T + t] = sum;
     }
 }
 
@@ -1008,6 +1037,8 @@ void launch_derive(const DevView &v, hipStream_t s, bool from_primal)
     if (from_primal) {        // serial over a node's agents: fine for tests / resume, not a hot path
         hipLaunchKernelGGL(k_derive_cons, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, v);
         if (v.S > 0) hipLaunchKernelGGL(k_derive_level, dim3((unsigned)((v.S + 255) / 256)), dim3(256), 0, s, v);
+        if (v.L > 0 && v.nGenItems + v.nStoItems > 0)
+            hipLaunchKernelGGL(k_derive_items, dim3(v.nGenItems + v.nStoItems), dim3(256), 0, s, v);
     }
     if (n1 <= kSmallConsensus) {
         hipLaunchKernelGGL(k_dual_price_small<false>, dim3(1), dim3(256), 0, s, v);

@@ -105,6 +105,9 @@ typedef struct dopf_params {
                                    of the single k_agents launch                                           */
 #define DOPF_F_COMM_HOST    64  /* dopf_multi_*: sum the consensus buffers through host memory instead of RCCL — a
                                    debugging transport that lets several shards share one device (tests)      */
+#define DOPF_F_KEEP_DELTAS  256  /* networks: keep every agent's injection change of the last iteration on the device, so that
+                                   dopf_get_agent_slacks / dopf_get_agent_penalty work without the caller passing it in (by
+                                   default it is written only for timesteps whose slack sums need the agents one by one) */
 #define DOPF_F_DEBUG_ROOT_CAP 128 /* tests: the scan kernel's root search gives up after 2 iterations instead of
                                    80, so that the DOPF_E_SOLVER path can be exercised                        */
 
@@ -158,12 +161,12 @@ int dopf_get_residual_vectors(dopf_ctx *ctx, double *lam_res /*T*/, double *mu_r
 /* ResultGenerator/ResultStorage.{U, K} of the last solve (src/structures/results.jl:1-17), L x T each,
  * [l + L*t]; agent = caller's index, generators 0..G-1 then storages G..G+S-1 (of this context's shard).
  * The device eliminates the slacks in closed form; they are recomputed here from the agent's injection
- * change and the consensus state that solve read. */
+ * change and the consensus state that solve read. Needs DOPF_F_KEEP_DELTAS. */
 int dopf_get_agent_slacks(dopf_ctx *ctx, int32_t agent, double *U, double *K);
 /* PenaltyTerm of the agent (src/structures/penalty_terms.jl:1-5, src/optimization/penalty_terms.jl:3-37):
  * penalty[0..T) energy_balance, [T..2T) upper_flow, [2T..3T) lower_flow — the diagnostics print_results shows
  * with print_penalty=true. delta = the agent's injection change of the last iteration (T values), or NULL to
- * use the device's copy, which exists only when L > 0 (DOPF_E_UNSUPPORTED otherwise). */
+ * use the device's copy, which exists only with lines and DOPF_F_KEEP_DELTAS (DOPF_E_UNSUPPORTED otherwise). */
 int dopf_get_agent_penalty(dopf_ctx *ctx, int32_t agent, const double *delta, double *penalty /*3*T*/);
 /* which = 0: duals used by the last solve (what the reference's driver script evaluates),
  * which = 1: duals after the last update. out is N x T, [n + N*t]. */

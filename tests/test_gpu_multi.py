@@ -111,9 +111,11 @@ def test_solver_failure_surfaces_as_an_error(hip_api):
 def test_agent_slacks_penalties_and_residual_vectors(hip_api, oracle_api):
     """ResultGenerator/ResultStorage.{U, K, penalty_term} and Convergence.*_res, recomputed on request."""
     pp = synth.synthetic_case(40, 8, 6, N=3, L=3, seed=21, fmax_factor=0.6, fmax_min=5)
-    h = make_engine(hip_api, pp, eps=0.0, gamma=0.05)
+    h = make_engine(hip_api, pp, eps=0.0, gamma=0.05, flags=_capi.F_KEEP_DELTAS)
     o = make_engine(oracle_api, pp, mode=1, eps=0.0, gamma=0.05)
     dp = _capi.c_double_p
+    with pytest.raises(_capi.DopfError):          # without the flag the device does not keep every agent's change
+        make_engine(hip_api, pp, eps=0.0, gamma=0.05).get_agent_slacks(0)
     for it in range(6):
         before = state_of(h)
         lam0, mu0, rho0 = h.get_duals()
