@@ -408,6 +408,26 @@ __device__ __forceinline__ void box2(double a, double b, double ia, double idet,
     sg = (fD && fC) ? s2 : ((fD || fC) ? ia : 0.0);
 }
 
+// 1/x to fp64 rounding without the ~30-instruction division sequence: hardware estimate + two Newton steps
+__device__ __forceinline__ double rcp64(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// box2 coefficients of a step whose Psi is linear with slope kap around the solution: a = w + kap, b = kap,
+// 1/a, 1/(a^2 - b^2) = (1/w) / (w + 2 kap), 2/(a + b) = 2 / (w + 2 kap) — rebuilt per evaluation from kap instead of
+// keeping three more arrays in registers (the kernels with lines sit at the VGPR limit)
+__device__ __forceinline__ void lin_coef(double w, double iw, double kap, double &ia, double &idet, double &s2)
+{
+    const double r2 = rcp64(w + 2.0 * kap);
+    ia = rcp64(w + kap);
+    idet = iw * r2;
+    s2 = 2.0 * r2;
+}
+
 // breakpoint table of Psi_{n,t} as one lane-timestep sees it
 struct TabRef {
     const double *beta, *psi, *slope;
@@ -514,20 +534,18 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
     }
     // with lines: a (node, timestep) whose table is empty — no kink of Psi inside the node's window, the usual case —
     // is the copper-plate closed form with (Psi(0), slope) in place of (theta, gamma): cached here, no table reads
-    double lp0[NCH], lkap[NCH], lia[NCH], lidet[NCH], ls2[NCH];
+    double lp0[NCH], lkap[NCH];
     bool lin[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int t = tbase + c;
-        lin[c] = false; lp0[c] = 0.0; lkap[c] = 0.0; lia[c] = 0.0; lidet[c] = 0.0; ls2[c] = 0.0;
+        lin[c] = false; lp0[c] = 0.0; lkap[c] = 0.0;
         if (LINES && t < T) {
             const size_t at = (size_t)it.node + (size_t)N * t;
             if (v.tb_m[at] == 0) {
                 lin[c] = true;
                 lp0[c] = v.tb_psi0[at];
                 lkap[c] = v.tb_slope[at * (v.M2 + 1)];
-                const double a = w + lkap[c];
-                lia[c] = 1.0 / a; lidet[c] = 1.0 / (a * a - lkap[c] * lkap[c]); ls2[c] = 2.0 / (a + lkap[c]);
             }
         }
     }
@@ -570,7 +588,9 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
                 pc = theta + gam * (dd - cc);
             } else if (lin[c]) {
                 const double q0 = D0[c] - C0[c], theta = lp0[c] - lkap[c] * q0;
-                box2(w + lkap[c], lkap[c], lia[c], lidet[c], ls2[c], w * D0[c] - ag.mc - theta - nu, w * C0[c] - ag.mc + theta + nu,
+                double lia, lidet, ls2;
+                lin_coef(w, iw, lkap[c], lia, lidet, ls2);
+                box2(w + lkap[c], lkap[c], lia, lidet, ls2, w * D0[c] - ag.mc - theta - nu, w * C0[c] - ag.mc + theta + nu,
                      ag.pm, dd, cc, s1);
                 pc = theta + lkap[c] * (dd - cc);
             } else {
@@ -807,7 +827,7 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
 }
 
 template <int LPS, int NCH, bool LINES>
-__global__ __launch_bounds__(256) void k_sto_update(DevView v)
+__global__ __launch_bounds__(256, 2) void k_sto_update(DevView v)
 {
     if (v.st->halt) return;
     sto_cold_body<LPS, NCH, LINES>(v, blockIdx.x, -1);
@@ -985,20 +1005,18 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
     }
     // with lines: a (node, timestep) whose table is empty — no kink of Psi inside the node's window, the usual case —
     // is the copper-plate closed form with (Psi(0), slope) in place of (theta, gamma): cached here, no table reads
-    double lp0[NCH], lkap[NCH], lia[NCH], lidet[NCH], ls2[NCH];
+    double lp0[NCH], lkap[NCH];
     bool lin[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int t = tbase + c;
-        lin[c] = false; lp0[c] = 0.0; lkap[c] = 0.0; lia[c] = 0.0; lidet[c] = 0.0; ls2[c] = 0.0;
+        lin[c] = false; lp0[c] = 0.0; lkap[c] = 0.0;
         if (LINES && t < T) {
             const size_t at = (size_t)it.node + (size_t)N * t;
             if (v.tb_m[at] == 0) {
                 lin[c] = true;
                 lp0[c] = v.tb_psi0[at];
                 lkap[c] = v.tb_slope[at * (v.M2 + 1)];
-                const double a = w + lkap[c];
-                lia[c] = 1.0 / a; lidet[c] = 1.0 / (a * a - lkap[c] * lkap[c]); ls2[c] = 2.0 / (a + lkap[c]);
             }
         }
     }
@@ -1043,7 +1061,9 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
                 box2(a0, gam, ia0, idet0, s20, A0[c] - nu, B0[c] + nu, pm, dd, cc, s1);
             } else if (lin[c]) {
                 const double q0 = A0[c] - B0[c], theta = lp0[c] - lkap[c] * q0;
-                box2(w + lkap[c], lkap[c], lia[c], lidet[c], ls2[c], w * A0[c] - mc - theta - nu, w * B0[c] - mc + theta + nu,
+                double lia, lidet, ls2;
+                lin_coef(w, iw, lkap[c], lia, lidet, ls2);
+                box2(w + lkap[c], lkap[c], lia, lidet, ls2, w * A0[c] - mc - theta - nu, w * B0[c] - mc + theta + nu,
                      pm, dd, cc, s1);
             } else {
                 double pc;
@@ -1445,7 +1465,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
 }
 
 template <int LPS, int NCH, bool LINES>
-__global__ __launch_bounds__(256) void k_sto_warm(DevView v)
+__global__ __launch_bounds__(256, 2) void k_sto_warm(DevView v)
 {
     if (v.st->halt) return;
     sto_warm_body<LPS, NCH, LINES>(v, blockIdx.x);
