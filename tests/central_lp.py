@@ -104,51 +104,8 @@ def aggregate_by_node(pp):
 
 
 def solve_central_nodal(pp):
-    """Same LP with explicit nodal injections I[n,t] = sum of the node's units - demand: the flow limits then have
-    N nonzeros per row instead of one per unit, which is what makes the 118-node / 12 500-agent share solvable."""
-    N, L, T, G, S = pp.N, pp.L, pp.T, pp.G, pp.S
-    nP, nS, nI = G * T, S * T, N * T
-    oD, oC, oE, oI = nP, nP + nS, nP + 2 * nS, nP + 3 * nS
-    nv = oI + nI
-    c = np.zeros(nv)
-    c[:nP] = np.repeat(pp.gen_mc, T)
-    c[oD:oD + nS] = np.repeat(pp.sto_mc, T)
-    c[oC:oC + nS] = np.repeat(pp.sto_mc, T)
-    lb = np.zeros(nv)
-    ub = np.concatenate([np.repeat(pp.gen_pmax, T), np.repeat(pp.sto_pmax, T), np.repeat(pp.sto_pmax, T),
-                         np.repeat(pp.sto_emax, T), np.full(nI, np.inf)])
-    lb[oI:] = -np.inf
-    tt = np.arange(T)
-    rows, cols, vals = [], [], []
-    # I[n,t] - sum units = -demand[n,t]      (row n*T + t)
-    gi = (np.repeat(pp.gen_node, T) * T + np.tile(tt, G))
-    rows.append(gi); cols.append(np.arange(nP)); vals.append(-np.ones(nP))
-    si = (np.repeat(pp.sto_node, T) * T + np.tile(tt, S))
-    rows.append(si); cols.append(oD + np.arange(nS)); vals.append(-np.ones(nS))
-    rows.append(si); cols.append(oC + np.arange(nS)); vals.append(np.ones(nS))
-    rows.append(np.arange(nI)); cols.append(oI + np.arange(nI)); vals.append(np.ones(nI))
-    beq = [-pp.demand.reshape(-1)]                       # demand is (N, T): index n*T + t
-    r0 = nI
-    # energy balance per timestep: sum_n I[n,t] = 0
-    rows.append(r0 + np.tile(tt, N)); cols.append(oI + np.arange(nI)); vals.append(np.ones(nI))
-    beq.append(np.zeros(T)); r0 += T
-    # storage dynamics E[t] - E[t-1] + D - C = 0
-    k = np.arange(nS)
-    rows += [r0 + k, r0 + k, r0 + k]; cols += [oE + k, oD + k, oC + k]; vals += [np.ones(nS), np.ones(nS), -np.ones(nS)]
-    k1 = k[(k % T) > 0]
-    rows.append(r0 + k1); cols.append(oE + k1 - 1); vals.append(-np.ones(k1.size))
-    beq.append(np.zeros(nS)); r0 += nS
-    Aeq = sparse.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(r0, nv))
-    Aub = bub = None
-    if L > 0:
-        # +-ptdf . I[., t] <= f_max
-        blocks = []
-        for sign in (1.0, -1.0):
-            blocks.append(sparse.kron(sparse.csr_matrix(sign * pp.ptdf), sparse.identity(T, format="csr"), format="csr"))
-        Aflow = sparse.vstack(blocks, format="csr")       # rows (l, t) = l*T + t, cols (n, t) = n*T + t
-        Aub = sparse.hstack([sparse.csr_matrix((Aflow.shape[0], oI)), Aflow], format="csr")
-        bub = np.tile(np.repeat(pp.f_max, T), 2)
-    res = linprog(c, A_ub=Aub, b_ub=bub, A_eq=Aeq, b_eq=np.concatenate(beq), bounds=np.stack([lb, ub], axis=1), method="highs")
-    if res.status != 0:
-        raise RuntimeError(res.message)
-    return dict(objective=res.fun)
+    """Same LP with explicit nodal injections (N non-zeros per flow row instead of one per unit): the product's
+    central reference, decentralopf.jl_amd/central.py (= src/opf_central_reference.jl)."""
+    from decentralopf_jl_amd.central import solve_central_packed
+    r = solve_central_packed(pp, duals=False)
+    return dict(objective=r.objective)

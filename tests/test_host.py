@@ -97,3 +97,25 @@ def test_shard_partitions_agents():
     assert sum(p.G for p in parts) == 23 and sum(p.S for p in parts) == 7
     assert np.array_equal(np.concatenate([p.gen_mc for p in parts]), pp.gen_mc)
     assert all(p.meta["n_agents_global"] == 30 for p in parts)
+
+
+def test_central_reference_reproduces_the_thesis_tables(three_node, thesis):
+    """decentralopf.jl_amd/central.py = src/opf_central_reference.jl: objective 14035, dispatch, flows, system price and
+    nodal prices of thesis Tables 8-16 (printed pp. 49-52)."""
+    nodes, lines, gens, stos, pp = three_node
+    r = pkg.central_reference(nodes, gens, stos, lines)
+    c = thesis["central"]
+    assert abs(r.objective - c["objective"]) < 1e-6
+    assert np.abs(r.generation - np.asarray(c["P"])).max() < 1e-6
+    assert np.abs(r.discharge[0] - np.asarray(c["D"])).max() < 1e-6 and np.abs(r.charge[0] - np.asarray(c["C"])).max() < 1e-6
+    assert np.abs(r.level[0] - np.asarray(c["E"])).max() < 1e-6
+    assert np.abs(r.line_utilization - np.asarray(c["flows"])).max() < 1e-6
+    assert np.abs(r.injection - np.asarray(c["injection"])).max() < 1e-6
+    assert np.abs(r.system_price - np.asarray(c["lambda"])).max() < 1e-6
+    assert np.abs(r.nodal_price - np.asarray(c["nodal_price"])).max() < 0.051          # the thesis prints one decimal
+    # the decentral run lands on it (sign of the prices flipped by construction, thesis p. 52)
+    t = thesis["admm"]
+    assert np.abs(-np.asarray(t["nodal_price"]) - r.nodal_price).max() < 0.05
+    # and the unit-wise formulation of the tests gives the same optimum
+    from central_lp import solve_central
+    assert abs(solve_central(pp)["objective"] - r.objective) < 1e-6
