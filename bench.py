@@ -117,7 +117,7 @@ def self_launch(args, argv):
     """--gpus N without a launcher: start the N ranks as children (this process never touches the GPU), relay
     rank 0's JSON line. A run that hangs is killed at the deadline and retried on the next communication mode."""
     import socket
-    modes = [args.comm] if args.comm != "auto" else ["lib", "lib-eager", "torch"]
+    modes = [args.comm] if args.comm != "auto" else ["lib", "torch"]
     last = ""
     rest, skip = [], False
     for a in argv:                      # the children get the mode of the attempt: drop --comm X / --comm=X
@@ -172,10 +172,11 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="fork the storage kernel onto a side stream")
     ap.add_argument("--flags", type=int, default=0, help="DOPF_F_* bits (include/dopf.h), e.g. 16 = separate generator/storage launches")
     ap.add_argument("--no-also", action="store_true", help="skip the short side runs of the other single-GPU workloads")
-    ap.add_argument("--comm", default="auto", choices=["auto", "lib", "lib-eager", "torch"],
-                    help="N > 1: who issues the all-reduce. lib = the library's own RCCL communicator, captured in the hipGraph "
-                         "(lib-eager: same, launched eagerly); torch = torch.distributed between two library calls. auto = lib, "
-                         "falling back in that order when this process launches the ranks itself")
+    ap.add_argument("--comm", default="auto", choices=["auto", "lib", "lib-graph", "torch"],
+                    help="N > 1: who issues the all-reduce. lib = the library's own RCCL communicator, plain launches without "
+                         "host synchronisation (lib-graph: the collective captured in the iteration hipGraph — exercised at world "
+                         "size 1 only so far); torch = torch.distributed between two library calls. auto = lib, falling back to "
+                         "torch when this process launches the ranks itself")
     ap.add_argument("--backend", default="nccl", help="--comm torch only: torch.distributed backend; nccl (= RCCL) is the product path, "
                                                       "gloo rehearses the multi-rank logic on a box with fewer GPUs than ranks")
     ap.add_argument("--force-sharded", action="store_true", help="debug: drive the sharded (all-reduce) path even on one rank")
@@ -208,7 +209,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     sharded = world > 1 or args.force_sharded
-    use_lib_comm = sharded and comm_mode in ("lib", "lib-eager")
+    use_lib_comm = sharded and comm_mode in ("lib", "lib-graph")
     if sharded:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
@@ -255,7 +256,7 @@ def main():
         sync = lambda: eng.sync()
     elif use_lib_comm:
         # every rank already holds its own grid; the library joins the ranks (RCCL) and owns the all-reduce
-        fl = args.flags | (_capi.F_NO_GRAPH if comm_mode == "lib-eager" else 0)
+        fl = args.flags | (_capi.F_COMM_GRAPH if comm_mode == "lib-graph" else 0)
         eng = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank, flags=fl,
                                                                         n_agents_global=A_global), **pp.engine_kwargs())
         box = [eng.comm_unique_id() if rank == 0 else None]
@@ -301,6 +302,14 @@ def main():
     clock_warm()
     step(args.warmup)
     sync()
+    if dist is not None and world > 1:
+        # every rank must hold the same duals: they are computed redundantly from the all-reduced sums. A collective
+        # that did not run (or ran out of order) shows up here, before anything is timed.
+        lam_here = torch.tensor(eng.get_duals()[0], dtype=torch.float64, device=ctl_dev)
+        lam_all = [torch.zeros_like(lam_here) for _ in range(world)]
+        dist.all_gather(lam_all, lam_here)
+        if any(not torch.equal(lam_all[0], x) for x in lam_all[1:]):
+            raise SystemExit(f"rank {rank}: duals differ across ranks after {args.warmup} iterations — the consensus all-reduce is broken")
     barrier()
     t0 = time.perf_counter()
     step(args.steps)
@@ -547,6 +556,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pp, gamma, w_flow, synth)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
+        eng.close()              # (communicator teardown while every rank is still there)
         dist.barrier()
         dist.destroy_process_group()
 

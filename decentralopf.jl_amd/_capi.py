@@ -57,6 +57,7 @@ F_NO_FUSE = 16
 F_COMM_HOST = 64
 F_DEBUG_ROOT_CAP = 128
 F_KEEP_DELTAS = 256
+F_COMM_GRAPH = 512
 COMM_ID_BYTES = 128
 
 

@@ -422,7 +422,10 @@ int dopf_iterate(dopf_ctx *c, int32_t n_iters, int32_t *iters_done, int32_t *con
     if (!c || n_iters < 0) return fail(c, DOPF_E_INVALID, "bad argument");
     DeviceGuard guard(c->device);
     const int before = c->host_st.iters_total;
-    bool eager = (c->q.flags & DOPF_F_NO_GRAPH) != 0;
+    // with a communicator of more than one rank the chain is launched eagerly unless the caller opts into capturing
+    // the collective (DOPF_F_COMM_GRAPH): either way nothing synchronises with the host inside the loop, and the
+    // host enqueues an iteration's four launches faster than the GPU retires them
+    bool eager = (c->q.flags & DOPF_F_NO_GRAPH) != 0 || (comm_world(c) > 1 && !(c->q.flags & DOPF_F_COMM_GRAPH));
     if (!eager && !c->graphs_valid) {
         int rc = build_graph(c, 1, &c->graph1);
         if (rc == DOPF_OK) rc = build_graph(c, kUnroll, &c->graphU);

@@ -8,8 +8,9 @@
 //
 // Two ways to get there, both ending in the same per-context chain
 //     k_agents ... k_reduce -> ncclAllReduce(consensus buffer, f64, sum, ctx stream) -> k_dual...
-// which dopf_iterate captures into its hipGraphs (RCCL collectives are capturable; if the capture is
-// refused the same chain is launched eagerly — still no host synchronisation per iteration):
+// which dopf_iterate launches without any host synchronisation per iteration: eagerly by default when the communicator
+// has more than one rank, captured into the iteration hipGraphs with DOPF_F_COMM_GRAPH (RCCL collectives are capturable;
+// if the capture is refused the chain falls back to eager launches). Capture has only been exercised at world size 1:
 //   * one process per GPU (torch.distributed.run, MPI, Distributed.jl ...): every rank creates its own
 //     context from its shard of the agents and calls dopf_comm_init(ctx, world, rank, id) with the 128-byte
 //     id of dopf_comm_unique_id, carried from rank 0 to the others over any host channel;
@@ -99,6 +100,8 @@ int comm_enqueue_allreduce(dopf_ctx *c)
     if (r != ncclSuccess) return fail(c, DOPF_E_DEVICE, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
     return DOPF_OK;
 }
+
+int comm_world(const dopf_ctx *c) { return c->comm ? c->comm->world : 1; }
 
 void comm_release(dopf_ctx *c)
 {

@@ -37,6 +37,7 @@ int read_status(dopf_ctx *c);
 // dopf_comm.hip
 int comm_enqueue_allreduce(dopf_ctx *c);      // sum of the consensus buffer over the ranks, on the context's stream
 void comm_release(dopf_ctx *c);
+int comm_world(const dopf_ctx *c);             // ranks of the context's communicator (1 without one)
 
 struct DeviceGuard {
     int prev = -1;

@@ -108,6 +108,9 @@ typedef struct dopf_params {
 #define DOPF_F_KEEP_DELTAS  256  /* networks: keep every agent's injection change of the last iteration on the device, so that
                                    dopf_get_agent_slacks / dopf_get_agent_penalty work without the caller passing it in (by
                                    default it is written only for timesteps whose slack sums need the agents one by one) */
+#define DOPF_F_COMM_GRAPH   512  /* contexts joined to a communicator of > 1 ranks: capture the RCCL all-reduce into the iteration
+                                   hipGraphs instead of launching the chain eagerly (default: eager — the host enqueues an
+                                   iteration faster than the GPU retires it, and plain launches are RCCL's best-trodden path) */
 #define DOPF_F_DEBUG_ROOT_CAP 128 /* tests: the scan kernel's root search gives up after 2 iterations instead of
                                    80, so that the DOPF_E_SOLVER path can be exercised                        */
 
@@ -203,8 +206,9 @@ int64_t dopf_solver_failures(dopf_ctx *ctx);
  * One process per GPU: every rank creates its context from its shard (dopf_problem.G/S = local agents,
  * dopf_params.n_agents_global = all agents), rank 0 calls dopf_comm_unique_id and ships the 128 bytes to
  * the other ranks over any host channel (MPI, torch.distributed, a file), every rank calls dopf_comm_init.
- * From then on dopf_iterate runs local_update -> all-reduce -> apply_consensus per iteration, captured in
- * its hipGraphs (launched eagerly if RCCL refuses the capture); no host round trip per iteration. */
+ * From then on dopf_iterate runs local_update -> all-reduce -> apply_consensus per iteration with no host round
+ * trip: plain launches by default, captured in its hipGraphs with DOPF_F_COMM_GRAPH (back to plain launches if RCCL
+ * refuses the capture). */
 #define DOPF_COMM_ID_BYTES 128
 int dopf_comm_unique_id(void *id128);
 int dopf_comm_init(dopf_ctx *ctx, int32_t world, int32_t rank, const void *id128);
