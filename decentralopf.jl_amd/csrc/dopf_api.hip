@@ -855,6 +855,14 @@ int dopf_debug_stats(dopf_ctx *c, uint64_t *out3 /* 15 values */)
     return DOPF_OK;
 }
 
+int dopf_debug_timeline(dopf_ctx *c, uint64_t *out, int32_t n)
+{
+    if (!c || !out) return DOPF_E_INVALID;
+    DeviceGuard guard(c->device);
+    hipStreamSynchronize(c->main);
+    return debug_timeline((unsigned long long *)out, n);
+}
+
 int64_t dopf_solver_failures(dopf_ctx *c)
 {
     if (!c) return -1;

@@ -108,6 +108,7 @@ void launch_gen_update(const DevView &v, hipStream_t s);
 void launch_sto_update(const DevView &v, const Launch &lc, hipStream_t s);
 void launch_agents_fused(const DevView &v, const Launch &lc, hipStream_t s);
 bool sto_config_supported(int T, Launch *lc);
+int debug_timeline(unsigned long long *out, int n);     // DOPF_STATS builds: per-wave stamps of the storage body
 // kernels_consensus.hip
 void launch_tables(const DevView &v, hipStream_t s);
 void launch_slack(const DevView &v, hipStream_t s);

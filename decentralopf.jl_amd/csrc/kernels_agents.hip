@@ -15,6 +15,13 @@
 
 namespace dopf {
 
+#ifdef DOPF_STATS
+__device__ unsigned long long g_timeline[8192 * 8];      // per wave of the storage body: wall-clock stamps (100 MHz)
+#define DOPF_STAMP(i) { if (lane == 0 && rep == 0 && round == 0) { const int w_ = blk * 4 + (tid >> 6); if (w_ < 8192) g_timeline[w_ * 8 + (i)] = wall_clock64(); } }
+#else
+#define DOPF_STAMP(i)
+#endif
+
 __device__ __forceinline__ double clampd(double v, double lo, double hi)
 {
     return fmin(fmax(v, lo), hi);
@@ -1029,6 +1036,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
 #define DOPF_TOC(i)
 #endif
     const int nRep = (it.a1 - it.a0 + NG - 1) / NG;
+    { const int rep = 0, round = 0; DOPF_STAMP(0) }
     for (int rep = 0; rep < nRep; ++rep) {
         const int s = it.a0 + rep * NG + grp;
         const bool live = s < it.a1;
@@ -1103,6 +1111,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
         }
 
         bool gdone = !live, good = false;
+        { const int round = 0; DOPF_STAMP(1) }
         for (int round = 0; round < MAXR; ++round) {
 #ifdef DOPF_STATS
             if (li == 0 && !gdone) ++st_rounds;
@@ -1156,6 +1165,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
 
             // ---- B. segmented Newton, bracketed --------------------------------------------------------------
             DOPF_TOC(0)
+            DOPF_STAMP(2)
             double px[NCH], ps[NCH], Dv[NCH], Cv[NCH];
             bool nconv = false, nfail = false;
             for (int itn = 0; itn < MAXN; ++itn) {
@@ -1280,6 +1290,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
             // choice that satisfies the sign condition at e whenever any does — with one suffix scan of
             // clamp maps, and the sign conditions are checked on that choice.
             DOPF_TOC(1)
+            DOPF_STAMP(3)
             bool okk = true;
             int nkind[NCH];
 #pragma unroll
@@ -1389,6 +1400,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
 
             // ---- D. accept, repair the contact set, or give up --------------------------------------------------
             DOPF_TOC(2)
+            DOPF_STAMP(4)
             if (!gdone && cert) {
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
@@ -1409,6 +1421,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
             }
             if (!gdone && (!nconv || !changed)) gdone = true;       // Newton stalled / nothing to repair: scan kernel
             DOPF_TOC(3)
+            DOPF_STAMP(5)
             if (__all(gdone)) break;
             if (!gdone) {
 #pragma unroll
@@ -1461,6 +1474,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
         __syncthreads();
     }
     if (tid == 0) { v.part_scost_w[blk] = redc[0]; v.item_fail[blk] = blockFail; }
+    { const int rep = 0, round = 0; DOPF_STAMP(6) }
     return blockFail;
 }
 
@@ -1501,6 +1515,16 @@ __global__ __launch_bounds__(256, 3) void k_agents(DevView v)
     } else {
         gen_pair_body<256>(v, blockIdx.x - nS);
     }
+}
+
+int debug_timeline(unsigned long long *out, int n)
+{
+#ifdef DOPF_STATS
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -1;
+#else
+    (void)out; (void)n;
+    return -1;
+#endif
 }
 
 bool sto_config_supported(int T, Launch *lc)

@@ -236,6 +236,8 @@ dopf_ctx *dopf_multi_ctx(dopf_multi *m, int32_t i);
  * active-set kernel certified in the LAST iteration, [4] storages it left to the scan kernel, [5..8] contact-set
  * rounds / Newton iterations (sum, max per lane group), [9..14] cycles per section (DOPF_STATS builds). */
 int dopf_debug_stats(dopf_ctx *ctx, uint64_t *out15);
+/* Diagnostics (-DDOPF_STATS builds; -1 otherwise): 8 wall-clock stamps (100 MHz) per wave of the storage body's last launch. */
+int dopf_debug_timeline(dopf_ctx *ctx, uint64_t *out, int32_t n);
 /* Diagnostics (L > 0): the breakpoint table of node n, timestep t that the last x-update used:
  * beta, psi: 2L doubles (first *m valid, ascending), slope: 2L+1, psi0 = Psi(0). */
 int dopf_debug_table(dopf_ctx *ctx, int32_t n, int32_t t, double *beta, double *psi, double *slope,
