@@ -258,7 +258,6 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     v.gamma = q->gamma; v.w_flow = q->w_flow; v.w_prox = q->w_prox; v.eps = q->eps; v.mask_thr = q->mask_thr;
     v.max_iters = q->max_iters;
     v.rootCap = (q->flags & DOPF_F_DEBUG_ROOT_CAP) ? 2 : 80;
-    v.dbg = q->flags >> 12;
     v.keepDeltas = (q->flags & DOPF_F_KEEP_DELTAS) ? 1 : 0;
     const int A = q->n_agents_global > 0 ? q->n_agents_global : G + S;
     v.invA = A > 0 ? 1.0 / (double)A : 0.0;
@@ -342,22 +341,16 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         for (int i = 0; i < S; ++i) win[snode[i]] = std::max(win[snode[i]], 2.0 * spm[i]);
         for (int n = 0; n < N; ++n) win[n] = win[n] * (1.0 + 1e-9) + 1e-9;
         TRY(dev_upload(c, &v.node_win, win));
-    }
-    TRY(dev_upload(c, &v.node_gitem_beg, ngib)); TRY(dev_upload(c, &v.node_sitem_beg, nsib));
-    {
         // per line: the largest |kap| W_n over the nodes, kap = w2 h / (w2 + gamma) — if the line's slack offset clears it,
         // every agent of every node has that slack active (or inactive) and the sums are a dot product (k_reduce)
         const double w2 = 2.0 * q->w_flow, inv = 1.0 / (w2 + q->gamma);
         std::vector<double> reach(L, 0.0);
-        std::vector<double> win(N, 0.0);
-        for (int i = 0; i < G; ++i) win[gnode[i]] = std::max(win[gnode[i]], gpm[i]);
-        for (int i = 0; i < S; ++i) win[snode[i]] = std::max(win[snode[i]], 2.0 * spm[i]);
-        for (int n = 0; n < N; ++n) win[n] = win[n] * (1.0 + 1e-9) + 1e-9;
         for (int l = 0; l < L; ++l)
             for (int n = 0; n < N; ++n) reach[l] = std::max(reach[l], std::fabs(w2 * p->ptdf[l + (size_t)L * n] * inv) * win[n]);
         for (int l = 0; l < L; ++l) reach[l] = reach[l] * (1.0 + 1e-9) + 1e-300;      // strictly beyond every node's own reach
         TRY(dev_upload(c, &v.line_reach, reach));
     }
+    TRY(dev_upload(c, &v.node_gitem_beg, ngib)); TRY(dev_upload(c, &v.node_sitem_beg, nsib));
     TRY(dev_alloc(c, &v.P, (size_t)G * T));
     TRY(dev_alloc(c, &v.gen_state, G));            // zero = "all zero", which is what P is now
     TRY(dev_alloc(c, &v.D, (size_t)S * T)); TRY(dev_alloc(c, &v.C, (size_t)S * T)); TRY(dev_alloc(c, &v.E, (size_t)S * T));

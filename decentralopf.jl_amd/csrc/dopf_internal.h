@@ -55,7 +55,6 @@ struct DevView {
     int use_warm;                   // storage warm-start kernel runs first; the scan kernel serves its failures
     int max_iters;
     int keepDeltas;                 // DOPF_F_KEEP_DELTAS: dltG / dltS are written for every timestep (diagnostic getters)
-    int dbg;                        // experiments: flags >> 8
     int rootCap;                    // iteration cap of the scan kernel's root search (80; 2 with DOPF_F_DEBUG_ROOT_CAP)
     double gamma, w_flow, w_prox, eps, mask_thr, invA;
     // problem (read-only)

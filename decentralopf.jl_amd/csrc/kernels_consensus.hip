@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void k_slack(DevView v, const int cap)
             if (!v.walk_flag[l + L * t]) continue;            // k_reduce takes the dot-product form
             const SlackCase c = slack_case(g, w2, inv, h[u], f[u], F[u], cu[u], ck[u], W);
             const size_t at = (size_t)n + (size_t)N * t;
-            // (closed-form and all-zero cases: k_reduce adds them from node_dsum)
+            // (closed-form and all-zero cases: k_reduce adds them from the node changes)
             if (!(c.aU - c.reach >= 0.0) && c.aU + c.reach > 0.0)
                 v.part_U[at * L + l] = walk_sum(v, dtile, tt, t, T, gb, ng, sb, na, cap, c.aU, -c.kap);
             if (!(c.aK - c.reach >= 0.0) && c.aK + c.reach > 0.0)
@@ -456,7 +456,6 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
         extern __shared__ double nsh[];               // [N] node changes of timestep t | [N] window | [N] agents at the node
         double *sdL = nsh, *winL = nsh + N, *naL = nsh + 2 * N;
         const int b2 = blockIdx.x - N * RB * TC, t = b2 >> 1, which = b2 & 1;
-        if (v.dbg & 1) return;
         for (int n = tid; n < N; n += 256) {
             sdL[n] = v.node_dsum[n + (size_t)N * t];
             winL[n] = v.node_win[n];
@@ -500,7 +499,7 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
             double hn[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) hn[u] = v.ptdf[l + (size_t)L * (u < N ? u : N - 1)];
-            for (int n0 = 0; n0 < ((v.dbg & 2) ? 8 : N); n0 += 8) {
+            for (int n0 = 0; n0 < N; n0 += 8) {
                 double h[8], x[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) h[u] = hn[u];

@@ -13,7 +13,7 @@ from oracle.binding import OracleApi
 ora = OracleApi(ge.ORACLE_LIB)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-worst_all, bad, warm_used = 0.0, 0, 0
+worst_all, bad, warm_used, left_total = 0.0, 0, 0, 0
 t0 = time.time()
 for k in range(n_cases):
     net = rng.random() < 0.35
@@ -43,6 +43,7 @@ for k in range(n_cases):
         scale = max(1.0, float(np.abs(so["lam"]).max()))
         worst, where = max_diff(sh, so, keys=["P", "D", "C", "E", "lam", "mu", "rho", "inj"])
         w_case = max(w_case, worst / scale)
+        left_total += h.warm_start_stats()[1]
         if worst > 1e-5 * scale:
             bad += 1
             print("MISMATCH", case, params, "emax/pmax", sorted(set(np.round(pp.sto_emax / pp.sto_pmax, 2).tolist())), "iteration", it, where, worst, flush=True)
@@ -56,4 +57,4 @@ for k in range(n_cases):
     h.close(); o.close()
     if k % 10 == 9:
         print(f"{k+1} cases, worst relative difference along the runs {worst_all:.2e}, bad {bad}, warm start carried {warm_used} cases at the end, {time.time()-t0:.0f}s", flush=True)
-print(f"done: {n_cases} cases, worst {worst_all:.2e}, bad {bad}")
+print(f"done: {n_cases} cases, worst {worst_all:.2e}, bad {bad}, storage solves left to the scan kernel over all iterations: {left_total}")
