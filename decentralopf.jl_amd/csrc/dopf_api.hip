@@ -299,7 +299,9 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     std::vector<int> ngb, nsb, ngib, nsib;
     {
         const int R = v.genTT2 ? v.genR2 : v.genR;
-        int chunk = std::max(R, (G + 2047) / 2048);
+        int target_items = 2048;
+        if (const char *e = getenv("DOPF_GEN_TARGET_ITEMS")) target_items = std::max(1, atoi(e));     // (experiments)
+        int chunk = std::max(R, (G + target_items - 1) / target_items);
         chunk = (chunk + R - 1) / R * R;
         make_items(gnode, N, chunk, gitems, ngb, ngib);
         // (on short blocks the skip test costs more than the rows it saves: measured on config1/config2)

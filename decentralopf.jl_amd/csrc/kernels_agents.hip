@@ -16,7 +16,7 @@
 namespace dopf {
 
 #ifdef DOPF_STATS
-__device__ unsigned long long g_timeline[8192 * 8];      // per wave of the storage body: wall-clock stamps (100 MHz)
+__device__ unsigned long long g_timeline[8192 * 8 + 8192 * 8];      // per wave of the storage body: wall-clock stamps (100 MHz)
 #define DOPF_STAMP(i) { if (lane == 0 && rep == 0 && round == 0) { const int w_ = blk * 4 + (tid >> 6); if (w_ < 8192) g_timeline[w_ * 8 + (i)] = wall_clock64(); } }
 #else
 #define DOPF_STAMP(i)
@@ -144,18 +144,31 @@ __device__ __forceinline__ void gen_pair_body(const DevView &v, const int blk)
         const double sh1 = fma(gam, v.s[t + 1], v.price[it.node + N * (t + 1)]) * inv;
         double2 *P2 = reinterpret_cast<double2 *>(v.P);
         const size_t half = (size_t)(T >> 1);
-#pragma unroll 4
-        for (int g = it.a0 + r; g < it.a1; g += R) {
-            const size_t e = (size_t)g * half + tt;
-            const double mc = v.gen_mc[g], pm = v.gen_pmax[g];
-            const double2 p0 = P2[e];
-            double2 pn;
-            // explicit fma: the row-skipping variant below must round exactly like this sweep
-            pn.x = clampd(p0.x - fma(mc, inv, sh0), 0.0, pm);
-            pn.y = clampd(p0.y - fma(mc, inv, sh1), 0.0, pm);
-            P2[e] = pn;
-            acc0 += pn.x; acc1 += pn.y;
-            cost = fma(mc, pn.x + pn.y, cost);
+        // rows in batches of GU: every load of the batch is issued before the first store (the compiler may not move a
+        // load across a store to the same array on its own), so a block keeps GU x 16 B per lane in flight — what lets the
+        // generator blocks of the fused launch stream while the storage blocks hold most of the wave slots
+        constexpr int GU = 4;
+        for (int g0 = it.a0 + r; g0 < it.a1; g0 += GU * R) {
+            double2 p0[GU];
+            double mc[GU], pm[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int g = g0 + u * R < it.a1 ? g0 + u * R : g0;          // (a valid row; result dropped below)
+                mc[u] = v.gen_mc[g]; pm[u] = v.gen_pmax[g];
+                p0[u] = P2[(size_t)g * half + tt];
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int g = g0 + u * R;
+                if (g >= it.a1) break;
+                double2 pn;
+                // explicit fma: the row-skipping variant below must round exactly like this sweep
+                pn.x = clampd(p0[u].x - fma(mc[u], inv, sh0), 0.0, pm[u]);
+                pn.y = clampd(p0[u].y - fma(mc[u], inv, sh1), 0.0, pm[u]);
+                P2[(size_t)g * half + tt] = pn;
+                acc0 += pn.x; acc1 += pn.y;
+                cost = fma(mc[u], pn.x + pn.y, cost);
+            }
         }
     }
     red[0][tid] = acc0; red[1][tid] = acc1;
@@ -1507,6 +1520,9 @@ __global__ __launch_bounds__(256, 3) void k_agents(DevView v)
 {
     if (v.st->halt) return;
     const int nS = v.nStoItems;
+#ifdef DOPF_STATS
+    if (threadIdx.x == 0 && blockIdx.x < 8192 * 4) g_timeline[32768 + 2 * blockIdx.x] = wall_clock64();
+#endif
     if ((int)blockIdx.x < nS) {
         const int left = sto_warm_body<LPS, NCH, false>(v, blockIdx.x);     // ends on a __syncthreads: its sto_fail
         sto_cold_body<LPS, NCH, false>(v, blockIdx.x, left);                // flags are visible to the block here
@@ -1515,6 +1531,10 @@ __global__ __launch_bounds__(256, 3) void k_agents(DevView v)
     } else {
         gen_pair_body<256>(v, blockIdx.x - nS);
     }
+#ifdef DOPF_STATS
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 8192 * 4) g_timeline[32768 + 2 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 int debug_timeline(unsigned long long *out, int n)
