@@ -147,7 +147,10 @@ __device__ __forceinline__ void gen_pair_body(const DevView &v, const int blk)
         // rows in batches of GU: every load of the batch is issued before the first store (the compiler may not move a
         // load across a store to the same array on its own), so a block keeps GU x 16 B per lane in flight — what lets the
         // generator blocks of the fused launch stream while the storage blocks hold most of the wave slots
-        constexpr int GU = 4;
+#ifndef DOPF_GU
+#define DOPF_GU 4
+#endif
+        constexpr int GU = DOPF_GU;
         for (int g0 = it.a0 + r; g0 < it.a1; g0 += GU * R) {
             double2 p0[GU];
             double mc[GU], pm[GU];
