@@ -911,6 +911,78 @@ __global__ __launch_bounds__(256) void k_dual_price_small(DevView v)
     const int tid = threadIdx.x;
     const size_t NT = (size_t)v.N * v.T, LT = (size_t)v.L * v.T;
     const size_t n1 = NT > LT ? NT : LT;
+    if (UPDATE && v.sliceDual && v.L == 0) {
+        // Copper plate, single-GPU chain (config1, config2, config4): the whole tail of the iteration in registers and
+        // LDS — slice sums, injections, imbalance, lambda step, prices, residual, stop test — with every global load
+        // issued up front and nothing read back from memory that this block has just written (the general path below
+        // pays an L2 round trip for each of cons -> inj -> lam -> price). Same arithmetic, same order of additions.
+        const int RB = v.reduceRB, N = v.N, T = v.T, R = 8;
+        const int r = tid >> 5, tt = tid & 31;
+        __shared__ double injL[256], lamL[256], wmax[4];
+        const size_t me = tid;                                // entry n + N*t of this thread in the later stages
+        const double dem = me < NT ? v.demand[me] : 0.0;
+        const double lam_old = tid < T ? v.lam[tid] : 0.0, s_old = tid < T ? v.s[tid] : 0.0;
+        const double cslice = tid < 64 && tid < RB ? v.part2_cost[tid] : 0.0;
+        double sc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const size_t i = (size_t)c * 32 + tt;
+            sc[c] = 0.0;
+            if (i < NT) {
+                const int n = (int)(i % N), t = (int)(i / N);
+                double x[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int q = r + R * k;
+                    x[k] = q < RB ? v.part2[((size_t)n * RB + q) * T + t] : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sc[c] += x[k];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) red[c][tid] = sc[c];
+        __syncthreads();
+        if (me < NT) {
+            const int c = (int)(me >> 5), t5 = (int)(me & 31);
+            double tot = 0.0;
+            for (int q = 0; q < R; ++q) tot += red[c][q * 32 + t5];
+            v.cons[me] = tot;
+            const double x = tot - dem;                       // results.jl:58-100
+            v.inj[me] = x;
+            injL[me] = x;
+        }
+        double ctot = cslice;                                 // cost slices: butterfly in wave 0 (a fixed order too)
+        if (tid < 64) {
+            for (int d = 32; d > 0; d >>= 1) ctot += __shfl_xor(ctot, d);
+            if (tid == 0) { v.cons[NT] = ctot; v.st->total_cost = ctot; }
+        }
+        __syncthreads();
+        double rl = 0.0;
+        if (tid < T) {
+            double sum = 0.0;
+            for (int n0 = 0; n0 < N; n0 += 8) {               // same grouping as dual_body
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = n0 + u < N ? injL[n0 + u + (size_t)N * tid] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum += x[u];
+            }
+            v.s_used[tid] = s_old;
+            v.s[tid] = sum;
+            const double ln = lam_old + v.gamma * sum;        // update_duals.jl:8-13
+            v.lam_used[tid] = lam_old;
+            v.lam[tid] = ln;
+            lamL[tid] = ln;
+            rl = fabs(ln - lam_old);
+        }
+        for (int d = 32; d > 0; d >>= 1) rl = fmax(rl, __shfl_xor(rl, d));
+        if ((tid & 63) == 0) wmax[tid >> 6] = rl;
+        __syncthreads();
+        if (me < NT) v.price[me] = lamL[me / N];              // no lines: the nodal price is lambda
+        if (tid == 0) status_update(v, fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3])), 0.0, 0.0);
+        return;
+    }
     if (UPDATE && v.sliceDual) {
         // level 2 of the consensus sum, here instead of behind a ticket in k_reduce: slice order, so the bits are
         // the ones the two-level kernel produces
