@@ -27,6 +27,26 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi)
     return fmin(fmax(v, lo), hi);
 }
 
+// 1/x to fp64 rounding without the ~30-instruction division sequence: hardware estimate + two Newton steps
+__device__ __forceinline__ double rcp64(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// box2 coefficients of a step whose Psi is linear with slope kap around the solution: a = w + kap, b = kap,
+// 1/a, 1/(a^2 - b^2) = (1/w) / (w + 2 kap), 2/(a + b) = 2 / (w + 2 kap) — rebuilt per evaluation from kap instead of
+// keeping three more arrays in registers (the kernels with lines sit at the VGPR limit)
+__device__ __forceinline__ void lin_coef(double w, double iw, double kap, double &ia, double &idet, double &s2)
+{
+    const double r2 = rcp64(w + 2.0 * kap);
+    ia = rcp64(w + kap);
+    idet = iw * r2;
+    s2 = 2.0 * r2;
+}
+
 // ------------------------------------------------------------------------------------------------
 // generators
 // ------------------------------------------------------------------------------------------------
@@ -72,6 +92,7 @@ __global__ __launch_bounds__(512) void k_gen_update(DevView v)
                 const double *slope = v.tb_slope + at * (v.M2 + 1);
                 const double psi0 = v.tb_psi0[at];
                 const double slope0 = slope[0];
+                const double inv0 = rcp64(slope0 + w);             // (empty table: one piece for every agent of the node)
                 const bool keepd = v.keepDeltas || v.walk_any[t];      // the change is needed agent by agent only for walked slack sums
                 for (int g0 = it.a0 + r; g0 < it.a1; g0 += 4 * R) {          // four agents' rows in flight per lane
                     double mc[4], pm[4], p0[4];
@@ -87,7 +108,7 @@ __global__ __launch_bounds__(512) void k_gen_update(DevView v)
                         const size_t e = (size_t)g * T + t;
                         double dl;
                         if (m == 0) {
-                            dl = -(mc[u] + psi0) / (slope0 + w);
+                            dl = -(mc[u] + psi0) * inv0;
                         } else {
                             int lo = 0, hi = m;           // first kink with psi + w beta >= -mc
                             while (lo < hi) {
@@ -95,7 +116,7 @@ __global__ __launch_bounds__(512) void k_gen_update(DevView v)
                                 if (psi[mid] + w * beta[mid] >= -mc[u]) hi = mid; else lo = mid + 1;
                             }
                             const int a = lo < m ? lo : m - 1;
-                            dl = beta[a] - (mc[u] + psi[a] + w * beta[a]) / (slope[lo] + w);
+                            dl = beta[a] - (mc[u] + psi[a] + w * beta[a]) * rcp64(slope[lo] + w);
                         }
                         const double pn = clampd(p0[u] + dl, 0.0, pm[u]);
                         v.P[e] = pn;
@@ -431,26 +452,6 @@ __device__ __forceinline__ void box2(double a, double b, double ia, double idet,
     sg = (fD && fC) ? s2 : ((fD || fC) ? ia : 0.0);
 }
 
-// 1/x to fp64 rounding without the ~30-instruction division sequence: hardware estimate + two Newton steps
-__device__ __forceinline__ double rcp64(double x)
-{
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-}
-
-// box2 coefficients of a step whose Psi is linear with slope kap around the solution: a = w + kap, b = kap,
-// 1/a, 1/(a^2 - b^2) = (1/w) / (w + 2 kap), 2/(a + b) = 2 / (w + 2 kap) — rebuilt per evaluation from kap instead of
-// keeping three more arrays in registers (the kernels with lines sit at the VGPR limit)
-__device__ __forceinline__ void lin_coef(double w, double iw, double kap, double &ia, double &idet, double &s2)
-{
-    const double r2 = rcp64(w + 2.0 * kap);
-    ia = rcp64(w + kap);
-    idet = iw * r2;
-    s2 = 2.0 * r2;
-}
-
 // breakpoint table of Psi_{n,t} as one lane-timestep sees it
 struct TabRef {
     const double *beta, *psi, *slope;
@@ -517,8 +518,9 @@ __device__ __forceinline__ void eval_lines(const TabRef &tb, int &hint, double w
     }
     const double theta = ap - kap * (ab + q0);
     const double a = w + kap;
-    box2(a, kap, 1.0 / a, 1.0 / (a * a - kap * kap), 2.0 / (a + kap), w * D0 - mc - theta - nu, w * C0 - mc + theta + nu,
-         pm, dd, cc, s1);
+    double ia, idet, s2;
+    lin_coef(w, iw, kap, ia, idet, s2);
+    box2(a, kap, ia, idet, s2, w * D0 - mc - theta - nu, w * C0 - mc + theta + nu, pm, dd, cc, s1);
     psi_cur = theta + kap * (dd - cc);       // Psi at the step's current net injection
 }
 
@@ -1270,7 +1272,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
                             const bool both = blo > -INFINITY && bhi < INFINITY;
                             double trial;
                             if (ps[c] > 0.0) {
-                                trial = nu - r / ps[c];
+                                trial = nu - r * rcp64(ps[c]);
                             } else {
                                 const double sd = fd_[t];                  // signed; +-inf when no kink lies ahead
                                 trial = nu + sd + copysign(1e-9 * (1.0 + fabs(nu) + fabs(sd)), sd);
