@@ -489,6 +489,18 @@ def main():
                     out["time_to_1e-3_residual"]["relative_gap_to_central_lp"] = \
                         abs(out["time_to_1e-3_residual"]["total_cost"] - opt["objective"]) / opt["objective"]
             e2.close()
+            # the central reference solved on the device (dopf_central_solve = src/opf_central_reference.jl as a first-order LP
+            # solve): the same target without a host LP
+            t0 = time.perf_counter()
+            cr = _capi.central_solve(_capi.hip_api(), tol=1e-7, max_iters=100000,
+                                     params=_capi.default_params(device=local_rank), **pp.engine_kwargs())
+            tcr = time.perf_counter() - t0
+            out["central_reference_on_device"] = {"objective": cr["objective"], "dual_objective": cr["dual_objective"],
+                                                  "primal_infeasibility": cr["primal_infeasibility"], "gap": cr["gap"],
+                                                  "iterations": cr["iterations"], "converged": cr["converged"], "seconds": tcr}
+            if conv2 and cr["converged"]:
+                out["time_to_1e-3_residual"]["relative_gap_to_device_central_reference"] = \
+                    abs(out["time_to_1e-3_residual"]["total_cost"] - cr["objective"]) / cr["objective"]
         if not sharded and not args.no_also and args.scale == 1.0:
             # the other BASELINE configurations that fit one GPU, same engine, short runs (reported, not the metric)
             also = []

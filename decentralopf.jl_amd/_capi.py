@@ -49,6 +49,11 @@ class DopfTiming(C.Structure):
                 ("agents_fused", C.c_int32)]
 
 
+class DopfCentralResult(C.Structure):
+    _fields_ = [("objective", C.c_double), ("dual_objective", C.c_double), ("primal_infeasibility", C.c_double),
+                ("gap", C.c_double), ("iterations", C.c_int32), ("converged", C.c_int32)]
+
+
 F_NO_GRAPH = 1
 F_OVERLAP_AGENTS = 2
 F_NO_WARM_START = 4
@@ -127,6 +132,8 @@ class CApi:
             self._sig("get_agent_slacks", C.c_int, [ctxp, C.c_int32, c_double_p, c_double_p])
             self._sig("get_agent_penalty", C.c_int, [ctxp, C.c_int32, c_double_p, c_double_p])
             self._sig("get_residual_vectors", C.c_int, [ctxp, c_double_p, c_double_p, c_double_p])
+            self._sig("central_solve", C.c_int, [C.POINTER(DopfProblem), C.POINTER(DopfParams), C.c_double, C.c_int32,
+                                                 C.POINTER(DopfCentralResult)] + [c_double_p] * 7)
             # consensus sum across GPUs inside the library (RCCL, loaded on first use)
             self._sig("comm_unique_id", C.c_int, [C.c_void_p])
             self._sig("comm_init", C.c_int, [ctxp, C.c_int32, C.c_int32, C.c_void_p])
@@ -437,3 +444,34 @@ class MultiEngine:
             base, rem = divmod(total, self.n)
             return base + (1 if i < rem else 0)
         return _ShardView(self.api, ctx, self.N, self.L, self.T, cut(self.G), cut(self.S))
+
+
+def central_solve(api: CApi, *, N, L, T, demand, ptdf, f_max, gen_mc, gen_pmax, gen_node, sto_mc, sto_pmax, sto_emax,
+                  sto_node, tol: float = 1e-8, max_iters: int = 200000, params: Optional[DopfParams] = None) -> dict:
+    """dopf_central_solve: the central reference (src/opf_central_reference.jl) as one LP solved on the GPU by a first-order
+    primal-dual method. Arguments as Engine (PackedProblem.engine_kwargs()). Returns objective, gap, iterations and the
+    reference script's outputs in Julia shapes: P (G,T), D/C/E (S,T), system_price (T), nodal_price (N,T),
+    line_utilization (L,T)."""
+    N, L, T = int(N), int(L), int(T)
+    gen_mc = _f64(gen_mc)
+    sto_mc = _f64(sto_mc)
+    G, S = gen_mc.size, sto_mc.size
+    keep = dict(demand=_f64(demand, N * T), ptdf=_f64(ptdf, L * N), f_max=_f64(f_max, L), gen_mc=gen_mc,
+                gen_pmax=_f64(gen_pmax, G), gen_node=_i32(gen_node, G), sto_mc=sto_mc, sto_pmax=_f64(sto_pmax, S),
+                sto_emax=_f64(sto_emax, S), sto_node=_i32(sto_node, S))
+    prob = DopfProblem(N=N, L=L, T=T, G=G, S=S)
+    for k, v in keep.items():
+        setattr(prob, k, v.ctypes.data_as(c_int32_p if v.dtype == np.int32 else c_double_p))
+    q = params if params is not None else default_params()
+    res = DopfCentralResult()
+    P, D, Cc, E = np.zeros(G * T), np.zeros(S * T), np.zeros(S * T), np.zeros(S * T)
+    lam, nodal, flow = np.zeros(T), np.zeros(N * T), np.zeros(L * T)
+    rc = api.central_solve(C.byref(prob), C.byref(q), float(tol), int(max_iters), C.byref(res), _dp(P), _dp(D), _dp(Cc), _dp(E),
+                           _dp(lam), _dp(nodal), _dp(flow))
+    if rc != 0:
+        msg = api.last_error(None)
+        raise DopfError(f"dopf_central_solve failed ({rc}): {msg.decode() if msg else ''}")
+    return dict(objective=res.objective, dual_objective=res.dual_objective, primal_infeasibility=res.primal_infeasibility,
+                gap=res.gap, iterations=res.iterations, converged=bool(res.converged),
+                P=P.reshape(G, T), D=D.reshape(S, T), C=Cc.reshape(S, T), E=E.reshape(S, T), system_price=lam,
+                nodal_price=nodal.reshape(T, N).T.copy(), line_utilization=flow.reshape(T, L).T.copy())

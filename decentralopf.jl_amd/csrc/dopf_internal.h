@@ -102,6 +102,26 @@ struct Launch {
     int stoLPS, stoNCH;
 };
 
+// the central reference's view (kernels_central.hip): the context's arrays (P, D, C, E, items, partial sums, cons) plus the
+// multipliers, running sums and step sizes of the primal-dual iteration
+struct CentralView {
+    DevView v;
+    double *yb, *yf, *yE;                   // multipliers: balance [T], flows [l + L*t], levels [t + T*s]
+    double *aP, *aD, *aC, *aE, *ab, *af;    // running sums of the iterates since the last restart
+    double *pi;                             // [n + N*t] yb + ptdf' yf of the candidate being worked on
+    const double *tauN;                     // [n] 1 / (1 + sum_l |ptdf[l,n]|): primal step of a generator at node n
+    const double *absHn;                    // [n] sum_l |ptdf[l,n]|
+    const double *sigF;                     // [l] 1 / sum_n |ptdf[l,n]| (units at n, a storage counting twice)
+    double sigB, w;                         // 1 / (G + 2S); primal weight
+    double *m_gen, *m_sto, *m_dual;         // metrics: per generator item [1], per storage item [3], per timestep [3]
+};
+
+// kernels_central.hip
+void central_launch_iteration(const CentralView &c, const DevView &vreduce, hipStream_t s);
+void central_launch_metrics(const CentralView &c, const DevView &vreduce, const double *XP, const double *XD, const double *XC,
+                            const double *XE, const double *yb, const double *yf, double scale, hipStream_t s);
+void central_launch_scale_copy(double *dst, const double *src, double scale, size_t n, hipStream_t s);
+
 // kernels_agents.hip
 void launch_gen_update(const DevView &v, hipStream_t s);
 void launch_sto_update(const DevView &v, const Launch &lc, hipStream_t s);

@@ -198,6 +198,22 @@ int dopf_iterate_timed(dopf_ctx *ctx, int32_t n_iters, dopf_timing *out);
 
 int64_t dopf_solver_failures(dopf_ctx *ctx);
 
+/* ---- the central reference on the device ---------------------------------------------------------------
+ * Replaces src/opf_central_reference.jl:16-81 (one JuMP model of the whole multi-period DC-OPF, solved by Gurobi): the same
+ * LP — variables P, D, C, E in their boxes, energy balance per timestep, |ptdf * injection| <= f_max, storage balance —
+ * solved on the GPU by a first-order primal-dual method (diagonal step sizes, averaging, restarts; csrc/kernels_central.hip).
+ * It is the parity target of the decentral run and independent of it. p holds ALL agents; q supplies device and flags.
+ * Stops when |primal - dual objective| / (1 + |primal|) + worst violation / (1 + max demand) <= tol, or at max_iters.
+ * Outputs (any may be NULL), layouts as in dopf_get_primal / dopf_get_consensus: P, D, C, E; system_price[T] = dual.(EB);
+ * nodal_price[N*T] = lambda + sum_l (dual FlowUpper + dual FlowLower)[l,t] ptdf[l,:]; line_utilization[L*T] = ptdf * I. */
+typedef struct dopf_central_result {
+    double objective, dual_objective, primal_infeasibility, gap;
+    int32_t iterations, converged;
+} dopf_central_result;
+int dopf_central_solve(const dopf_problem *p, const dopf_params *q, double tol, int32_t max_iters,
+                       dopf_central_result *res, double *P, double *D, double *C, double *E,
+                       double *system_price, double *nodal_price, double *line_utilization);
+
 /* ---- consensus sum across GPUs inside the library (RCCL over xGMI, loaded at run time) -------------
  * Replaces nothing in the reference (it has no parallelism); what is distributed is the agent loop of
  * optimize_all_subproblems! (src/optimization/subproblems.jl:1-17) and the agent sums of Result(...)

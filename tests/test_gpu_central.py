@@ -1,0 +1,57 @@
+"""The central reference on the device (dopf_central_solve, csrc/kernels_central.hip = src/opf_central_reference.jl as a
+first-order LP solve) against the thesis tables, the host LP (decentralopf.jl_amd/central.py, HiGHS) and the fixtures."""
+import numpy as np
+import pytest
+
+from decentralopf_jl_amd import _capi, synth
+from decentralopf_jl_amd.central import solve_central_packed
+
+pytestmark = pytest.mark.gpu
+
+
+def test_three_node_case_matches_the_thesis_tables(hip_api, three_node, thesis):
+    pp = three_node[4]
+    r = _capi.central_solve(hip_api, tol=1e-9, **pp.engine_kwargs())
+    c = thesis["central"]
+    assert r["converged"] and abs(r["objective"] - c["objective"]) < 1e-4 and r["primal_infeasibility"] < 1e-6
+    assert abs(r["dual_objective"] - c["objective"]) < 1e-3
+    assert np.abs(r["P"] - np.asarray(c["P"])).max() < 1e-4
+    assert np.abs(r["D"][0] - np.asarray(c["D"])).max() < 1e-4 and np.abs(r["C"][0] - np.asarray(c["C"])).max() < 1e-4
+    assert np.abs(r["E"][0] - np.asarray(c["E"])).max() < 1e-4
+    assert np.abs(r["line_utilization"] - np.asarray(c["flows"])).max() < 1e-4
+    assert np.abs(r["system_price"] - np.asarray(c["lambda"])).max() < 1e-3
+    assert np.abs(r["nodal_price"] - np.asarray(c["nodal_price"])).max() < 0.051         # the thesis prints one decimal
+
+
+@pytest.mark.parametrize("name", ["config1", "copper T96", "network 6x9", "network 118x186"])
+def test_objective_matches_the_host_lp(hip_api, name):
+    from conftest import load_golden
+    if name == "config1":
+        pp = synth.baseline_config(1)
+        want = load_golden("synthetic_optima")["config1"]["objective"]
+    else:
+        pp = {"copper T96": lambda: synth.synthetic_case(700, 90, 96, seed=5),
+              "network 6x9": lambda: synth.synthetic_case(60, 15, 24, N=6, L=9, seed=7, fmax_factor=1.0, fmax_min=5),      # limits bind
+              "network 118x186": lambda: synth.synthetic_case(900, 90, 24, N=118, L=186, seed=19)}[name]()
+        want = solve_central_packed(pp, duals=False).objective
+    r = _capi.central_solve(hip_api, tol=1e-7, **pp.engine_kwargs())
+    assert r["converged"], r
+    assert abs(r["objective"] - want) <= 1e-5 * abs(want) and abs(r["dual_objective"] - want) <= 1e-5 * abs(want)
+    assert r["primal_infeasibility"] <= 1e-5 * (1.0 + np.abs(pp.demand).max())
+    # what comes back is feasible in its own right
+    assert r["P"].min() >= 0 and (r["P"] - pp.gen_pmax[:, None]).max() <= 0
+    assert np.abs(np.cumsum(r["C"] - r["D"], axis=1) - r["E"]).max() < 1e-9 * (1 + np.abs(r["E"]).max())
+    cost = float(pp.gen_mc @ r["P"].sum(axis=1) + pp.sto_mc @ (r["D"] + r["C"]).sum(axis=1))
+    assert abs(cost - r["objective"]) <= 1e-10 * cost
+
+
+def test_decentral_run_lands_on_the_device_central_optimum(hip_api):
+    """BASELINE's third target, without any host LP: ADMM's converged cost against dopf_central_solve on config2."""
+    from helpers import make_engine
+    pp = synth.baseline_config(2)
+    r = _capi.central_solve(hip_api, tol=1e-7, **pp.engine_kwargs())
+    assert r["converged"]
+    e = make_engine(hip_api, pp, gamma=1.0 / (pp.G + pp.S), max_iters=5000)
+    done, conv = e.iterate(5000)
+    assert conv
+    assert abs(e.get_consensus()[4] - r["objective"]) / r["objective"] < 1e-3
