@@ -5,7 +5,7 @@ The directory name contains a dot, so it is loaded through ``dopf_pkg.load()`` (
 the module name ``decentralopf_jl_amd``.
 """
 from . import _capi, admm, central, network, sharded, synth
-from .central import CentralResult, central_reference, solve_central_packed
+from .central import CentralResult, central_reference, central_reference_on_device, solve_central_packed
 from .admm import ADMM, calculate_iteration, export_results, get_nodal_price, run
 from .sharded import ShardedADMM
 from ._capi import DopfError, Engine, default_params, hip_api
@@ -16,4 +16,4 @@ __all__ = ["DopfError", "Engine", "default_params", "hip_api", "Generator", "Lin
            "PackedProblem", "Storage", "calculate_ptdf", "pack", "three_node_case", "_capi",
            "network", "synth", "admm", "sharded", "ADMM", "calculate_iteration",
            "export_results", "get_nodal_price", "run", "ShardedADMM", "central", "CentralResult",
-           "central_reference", "solve_central_packed"]
+           "central_reference", "central_reference_on_device", "solve_central_packed"]

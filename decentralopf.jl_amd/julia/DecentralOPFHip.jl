@@ -296,3 +296,53 @@ function get_nodal_price(iteration::Int)
     end
     return nodal_price
 end
+
+struct CCentralResult          # == struct dopf_central_result (include/dopf.h)
+    objective::Cdouble
+    dual_objective::Cdouble
+    primal_infeasibility::Cdouble
+    gap::Cdouble
+    iterations::Cint
+    converged::Cint
+end
+
+"""
+    central_reference(nodes, generators, storages, lines; tol = 1e-9, max_iters = 200000)
+
+What src/opf_central_reference.jl computes — objective, P, D, C, line utilisation, system price `dual.(EB)`, nodal price —
+from the whole problem as ONE LP, solved on the GPU by libdopf_hip's first-order method (no modelling layer, no licensed solver).
+Returns a NamedTuple; matrices are units x timesteps like `value.(P).data`.
+"""
+function central_reference(nodes::Vector{Node}, generators::Vector{Generator}, storages::Vector{Storage}, lines::Vector{Line};
+                           tol::Float64=1e-9, max_iters::Int=200000, device::Int=-1)
+    N, L, T = length(nodes), length(lines), length(nodes[1].demand)
+    G, S = length(generators), length(storages)
+    node_to_id = Dict{Node, Int}(n => i for (i, n) in enumerate(nodes))
+    demand = Float64[nodes[n].demand[t] for n in 1:N, t in 1:T]
+    ptdf = L > 0 ? Matrix{Float64}(calculate_ptdf(nodes, lines)) : zeros(Float64, 0, N)
+    f_max = Float64[l.max_capacity for l in lines]
+    gen_mc = Float64[g.marginal_costs for g in generators]
+    gen_pmax = Float64[g.max_generation for g in generators]
+    gen_node = Cint[node_to_id[g.node] - 1 for g in generators]
+    sto_mc = Float64[s.marginal_costs for s in storages]
+    sto_pmax = Float64[s.max_power for s in storages]
+    sto_emax = Float64[s.max_level for s in storages]
+    sto_node = Cint[node_to_id[s.node] - 1 for s in storages]
+    P = zeros(T, G); D = zeros(T, S); C = zeros(T, S); E = zeros(T, S)
+    lambda = zeros(T); nodal = zeros(N, T); util = zeros(L, T)
+    res = Ref(CCentralResult(0.0, 0.0, 0.0, 0.0, 0, 0))
+    GC.@preserve demand ptdf f_max gen_mc gen_pmax gen_node sto_mc sto_pmax sto_emax sto_node begin
+        prob = Ref(CProblem(N, L, T, G, S, pointer(demand), pointer(ptdf), pointer(f_max), pointer(gen_mc),
+                            pointer(gen_pmax), pointer(gen_node), pointer(sto_mc), pointer(sto_pmax),
+                            pointer(sto_emax), pointer(sto_node)))
+        par = Ref(CParams(0.3, 10.0, 1.0, 1e-3, 1e-2, 0, 0, device, 0, C_NULL))
+        rc = ccall((:dopf_central_solve, DOPF_LIB), Cint,
+                   (Ref{CProblem}, Ref{CParams}, Cdouble, Cint, Ref{CCentralResult}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
+                    Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                   prob, par, tol, max_iters, res, P, D, C, E, lambda, nodal, util)
+        dopf_check(rc, Ptr{Cvoid}(C_NULL))
+    end
+    res[].converged == 0 && error("central LP: gap $(res[].gap) after $(res[].iterations) iterations")
+    return (objective=res[].objective, generation=permutedims(P), discharge=permutedims(D), charge=permutedims(C),
+            level=permutedims(E), line_utilization=util, system_price=lambda, nodal_price=nodal)
+end

@@ -32,7 +32,7 @@ def c_struct_fields(name):
 
 
 def jl_struct_fields(name):
-    body = re.search(r"^struct %s\n(.*?)^end" % name, CODE, re.S | re.M).group(1)
+    body = re.search(r"^struct %s[ \t]*\n(.*?)^end" % name, CODE, re.S | re.M).group(1)
     out = []
     for part in re.split(r"[;\n]", body):
         part = part.strip()
@@ -75,6 +75,17 @@ def test_every_ccall_matches_a_header_prototype():
                  "dopf_get_primal", "dopf_get_consensus", "dopf_get_residuals", "dopf_multi_create", "dopf_multi_iterate",
                  "dopf_multi_destroy"):
         assert need in used, need
+
+
+def test_central_result_mirror_matches_the_header():
+    body = re.search(r"typedef struct dopf_central_result \{(.*?)\} dopf_central_result;", HDR, re.S).group(1)
+    want = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if decl:
+            ctype, names = decl.split(" ", 1)
+            want += [(n.strip(), C2JL[ctype]) for n in names.split(",")]
+    assert jl_struct_fields("CCentralResult") == want
 
 
 def test_it_is_a_drop_in_for_imports_jl():
