@@ -22,7 +22,7 @@ using namespace dopf;
 
 namespace {
 
-constexpr int kUnroll = 16;
+constexpr int kUnroll = 16, kMid = 4;
 constexpr int kCheckEvery = 512;
 thread_local char g_create_err[512];
 
@@ -129,8 +129,9 @@ void enqueue_apply(dopf_ctx *c, bool single)
 void drop_graphs(dopf_ctx *c)
 {
     if (c->graph1) hipGraphExecDestroy(c->graph1);
+    if (c->graphM) hipGraphExecDestroy(c->graphM);
     if (c->graphU) hipGraphExecDestroy(c->graphU);
-    c->graph1 = c->graphU = nullptr;
+    c->graph1 = c->graphM = c->graphU = nullptr;
     c->graphs_valid = false;
 }
 
@@ -425,6 +426,7 @@ int dopf_iterate(dopf_ctx *c, int32_t n_iters, int32_t *iters_done, int32_t *con
     bool eager = (c->q.flags & DOPF_F_NO_GRAPH) != 0 || (comm_world(c) > 1 && !(c->q.flags & DOPF_F_COMM_GRAPH));
     if (!eager && !c->graphs_valid) {
         int rc = build_graph(c, 1, &c->graph1);
+        if (rc == DOPF_OK) rc = build_graph(c, kMid, &c->graphM);
         if (rc == DOPF_OK) rc = build_graph(c, kUnroll, &c->graphU);
         if (rc) {
             if (!c->comm) return rc;
@@ -447,6 +449,7 @@ int dopf_iterate(dopf_ctx *c, int32_t n_iters, int32_t *iters_done, int32_t *con
             for (int i = 0; i < slice; ++i) { const int rc = enqueue_iteration(c); if (rc) return rc; }
         } else {
             for (; slice >= kUnroll; slice -= kUnroll) HIPCHK(c, hipGraphLaunch(c->graphU, c->main));
+            for (; slice >= kMid; slice -= kMid) HIPCHK(c, hipGraphLaunch(c->graphM, c->main));
             for (; slice > 0; --slice) HIPCHK(c, hipGraphLaunch(c->graph1, c->main));
         }
         HIPCHK(c, hipGetLastError());

@@ -16,7 +16,7 @@ struct dopf_ctx {
     hipStream_t main = nullptr, side = nullptr;
     bool own_main = false;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
-    hipGraphExec_t graph1 = nullptr, graphU = nullptr;
+    hipGraphExec_t graph1 = nullptr, graphM = nullptr, graphU = nullptr;   // 1, kMid, kUnroll iterations per launch
     bool graphs_valid = false;
     std::vector<void *> allocs;
     void *own_cons = nullptr;
