@@ -117,7 +117,9 @@ def self_launch(args, argv):
     """--gpus N without a launcher: start the N ranks as children (this process never touches the GPU), relay
     rank 0's JSON line. A run that hangs is killed at the deadline and retried on the next communication mode."""
     import socket
-    modes = [args.comm] if args.comm != "auto" else ["lib", "torch"]
+    # auto: the ranks try the library communicator and fall back to torch in place when it raises; a hang is this
+    # watchdog's business, and the second attempt then goes straight to torch
+    modes = [args.comm] if args.comm != "auto" else ["auto", "torch"]
     last = ""
     rest, skip = [], False
     for a in argv:                      # the children get the mode of the attempt: drop --comm X / --comm=X
@@ -190,7 +192,6 @@ def main():
         # the driver's N = 1 form of the command with N > 1: be the launcher (no GPU call has happened in this process)
         raise SystemExit(self_launch(args, sys.argv[1:]))
     args.gpus = world
-    comm_mode = "lib" if args.comm == "auto" else args.comm
 
     # stdout carries exactly ONE line (the JSON record): libraries that chat on stdout (RCCL prints a
     # version banner at communicator creation) are sent to stderr for the whole run
@@ -209,20 +210,27 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     sharded = world > 1 or args.force_sharded
-    use_lib_comm = sharded and comm_mode in ("lib", "lib-graph")
+    # transports to try, in order. Started by a launcher with --comm auto, a transport that raises (on any rank) or leaves
+    # the ranks with different duals is given up IN PLACE and the next one is set up: the run still ends in a JSON line.
+    # (A transport that hangs can only be handled from outside: self_launch's watchdog.)
+    modes = (["lib", "torch"] if args.comm == "auto" else [args.comm]) if sharded else ["single"]
+    data_group = None
     if sharded:
+        import datetime
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
-        if use_lib_comm:
+        if modes[0] in ("lib", "lib-graph") or args.backend != "nccl":
             # control plane only (unique id, demand sum, barriers, max of the times): gloo on host tensors.
             # The data path — the per-iteration consensus sum — is the library's own RCCL communicator.
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        elif args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("gloo" if modes[0] in ("lib", "lib-graph") else args.backend, rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=600))
+            ctl_dev = "cpu"
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-    ctl_dev = "cpu" if (use_lib_comm or args.backend != "nccl") else "cuda"
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            ctl_dev = "cuda"
+    else:
+        ctl_dev = "cpu"
 
     desc = WORKLOADS[args.workload][1]
     # weak scaling: every rank owns one full grid of the workload (own seed), demand adds up
@@ -248,36 +256,36 @@ def main():
     w_flow = args.w_flow if args.w_flow is not None else (10.0 if pp.L == 0 else 0.3 / A_global)
     comm_info = None
 
-    if not sharded:
-        eng = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank,
-                                                                        flags=args.flags | (_capi.F_OVERLAP_AGENTS if args.overlap else 0)),
-                           **pp.engine_kwargs())
-        step = lambda n: eng.iterate(n)
-        sync = lambda: eng.sync()
-    elif use_lib_comm:
-        # every rank already holds its own grid; the library joins the ranks (RCCL) and owns the all-reduce
-        fl = args.flags | (_capi.F_COMM_GRAPH if comm_mode == "lib-graph" else 0)
-        eng = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank, flags=fl,
-                                                                        n_agents_global=A_global), **pp.engine_kwargs())
-        box = [eng.comm_unique_id() if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(box, src=0)
-        eng.comm_init(world, rank, box[0])
-        step = lambda n: eng.iterate(n)
-        sync = lambda: eng.sync()
-    else:
+    def set_up(mode):
+        """-> (engine, step(n), sync(), close()) for one transport"""
+        if mode == "single":
+            e = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank,
+                                                                          flags=args.flags | (_capi.F_OVERLAP_AGENTS if args.overlap else 0)),
+                             **pp.engine_kwargs())
+            return e, e.iterate, e.sync, e.close
+        if mode in ("lib", "lib-graph"):
+            # every rank already holds its own grid; the library joins the ranks (RCCL) and owns the all-reduce
+            fl = args.flags | (_capi.F_COMM_GRAPH if mode == "lib-graph" else 0)
+            e = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank, flags=fl,
+                                                                          n_agents_global=A_global), **pp.engine_kwargs())
+            box = [e.comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            e.comm_init(world, rank, box[0])
+            return e, e.iterate, e.sync, e.close
         from decentralopf_jl_amd.sharded import ShardedADMM
         # every rank already holds its own grid: a 1-way "shard" of its local problem, global agent count
         # passed explicitly; the all-reduce runs over all ranks on the engine's own stream
+        nonlocal data_group
+        if ctl_dev == "cpu" and args.backend == "nccl" and data_group is None:
+            data_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # control plane stays on gloo
         sh = ShardedADMM(pp, 0, 1, gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank, n_agents_global_override=A_global)
         tens = sh._tensor
 
         def _all_reduce():                # (ShardedADMM.step makes the engine's stream current around its loop)
-            dist.all_reduce(tens, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tens, op=dist.ReduceOp.SUM, group=data_group)
         sh._all_reduce = _all_reduce
-        eng = sh.engine
-        step = lambda n: sh.step(n)
-        sync = lambda: sh.sync()
+        return sh.engine, sh.step, sh.sync, sh.engine.close
 
     def barrier():
         torch.cuda.synchronize()
@@ -299,17 +307,46 @@ def main():
                 _wm["b"] = _wm["a"] @ _wm["a"]
             torch.cuda.synchronize()
 
+    def all_ranks(ok):
+        if dist is None or world == 1:
+            return ok
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ctl_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
     clock_warm()
-    step(args.warmup)
-    sync()
-    if dist is not None and world > 1:
-        # every rank must hold the same duals: they are computed redundantly from the all-reduced sums. A collective
-        # that did not run (or ran out of order) shows up here, before anything is timed.
-        lam_here = torch.tensor(eng.get_duals()[0], dtype=torch.float64, device=ctl_dev)
-        lam_all = [torch.zeros_like(lam_here) for _ in range(world)]
-        dist.all_gather(lam_all, lam_here)
-        if any(not torch.equal(lam_all[0], x) for x in lam_all[1:]):
-            raise SystemExit(f"rank {rank}: duals differ across ranks after {args.warmup} iterations — the consensus all-reduce is broken")
+    comm_mode, given_up = None, []
+    for mode in modes:
+        ok, why, closer = True, "", None
+        try:
+            eng, step, sync, closer = set_up(mode)
+            step(args.warmup)
+            sync()
+        except Exception as e:                      # noqa: BLE001 — whatever the transport raised
+            ok, why = False, f"{type(e).__name__}: {e}"
+        if not all_ranks(ok):
+            why = why or "another rank failed"
+        elif world > 1:
+            # every rank must hold the same duals: they are computed redundantly from the all-reduced sums. A collective
+            # that did not run (or ran out of order) shows up here, before anything is timed.
+            lam_here = torch.tensor(eng.get_duals()[0], dtype=torch.float64, device=ctl_dev)
+            lam_all = [torch.zeros_like(lam_here) for _ in range(world)]
+            dist.all_gather(lam_all, lam_here)
+            if any(not torch.equal(lam_all[0], x) for x in lam_all[1:]):
+                why = f"duals differ across ranks after {args.warmup} iterations — the consensus all-reduce did not do its job"
+        if not why:
+            comm_mode = mode
+            break
+        given_up.append({"mode": mode, "why": why})
+        print(f"bench.py rank {rank}: transport {mode} given up ({why})", file=sys.stderr)
+        if closer is not None:
+            try:
+                closer()
+            except Exception:                       # noqa: BLE001
+                pass
+    if comm_mode is None:
+        raise SystemExit(f"rank {rank}: no transport worked: {given_up}")
+    use_lib_comm = comm_mode in ("lib", "lib-graph")
     barrier()
     t0 = time.perf_counter()
     step(args.steps)
@@ -330,6 +367,8 @@ def main():
     elif sharded:
         comm_info = {"transport": f"torch.distributed ({args.backend}) all-reduce between dopf_local_update and dopf_apply_consensus",
                      "world": world, "captured_in_hipgraph": False}
+    if comm_info is not None and given_up:
+        comm_info["transports_given_up"] = given_up
 
     # Per-kernel durations, live, HIP events on the stream the kernels run on. The timed region above replays
     # hipGraphs (no place for events), so the SAME iterations — W warm-up, then K — are run again on a fresh engine,
