@@ -174,11 +174,12 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="fork the storage kernel onto a side stream")
     ap.add_argument("--flags", type=int, default=0, help="DOPF_F_* bits (include/dopf.h), e.g. 16 = separate generator/storage launches")
     ap.add_argument("--no-also", action="store_true", help="skip the short side runs of the other single-GPU workloads")
-    ap.add_argument("--comm", default="auto", choices=["auto", "lib", "lib-graph", "torch"],
-                    help="N > 1: who issues the all-reduce. lib = the library's own RCCL communicator, plain launches without "
-                         "host synchronisation (lib-graph: the collective captured in the iteration hipGraph — exercised at world "
-                         "size 1 only so far); torch = torch.distributed between two library calls. auto = lib, falling back to "
-                         "torch when this process launches the ranks itself")
+    ap.add_argument("--comm", default="auto", choices=["auto", "p2p", "lib", "lib-graph", "torch"],
+                    help="N > 1: how the consensus vector is summed over the ranks. p2p = the library's peer exchange (one kernel "
+                         "per iteration, direct stores into the peers' memory); lib = the library's own RCCL communicator, plain "
+                         "launches without host synchronisation (lib-graph: the collective captured in the iteration hipGraph); "
+                         "torch = torch.distributed between two library calls. auto = p2p, then lib, then torch: a transport that "
+                         "raises or fails its checks is given up in place")
     ap.add_argument("--backend", default="nccl", help="--comm torch only: torch.distributed backend; nccl (= RCCL) is the product path, "
                                                       "gloo rehearses the multi-rank logic on a box with fewer GPUs than ranks")
     ap.add_argument("--force-sharded", action="store_true", help="debug: drive the sharded (all-reduce) path even on one rank")
@@ -199,6 +200,7 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    import numpy as np
     import torch
     import dopf_pkg
     dopf_pkg.load()
@@ -213,17 +215,17 @@ def main():
     # transports to try, in order. Started by a launcher with --comm auto, a transport that raises (on any rank) or leaves
     # the ranks with different duals is given up IN PLACE and the next one is set up: the run still ends in a JSON line.
     # (A transport that hangs can only be handled from outside: self_launch's watchdog.)
-    modes = (["lib", "torch"] if args.comm == "auto" else [args.comm]) if sharded else ["single"]
+    modes = (["p2p", "lib", "torch"] if args.comm == "auto" else [args.comm]) if sharded else ["single"]
     data_group = None
     if sharded:
         import datetime
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
-        if modes[0] in ("lib", "lib-graph") or args.backend != "nccl":
+        if modes[0] in ("p2p", "lib", "lib-graph") or args.backend != "nccl":
             # control plane only (unique id, demand sum, barriers, max of the times): gloo on host tensors.
             # The data path — the per-iteration consensus sum — is the library's own RCCL communicator.
-            dist.init_process_group("gloo" if modes[0] in ("lib", "lib-graph") else args.backend, rank=rank, world_size=world,
+            dist.init_process_group("gloo" if modes[0] in ("p2p", "lib", "lib-graph") else args.backend, rank=rank, world_size=world,
                                     timeout=datetime.timedelta(seconds=600))
             ctl_dev = "cpu"
         else:
@@ -262,6 +264,19 @@ def main():
             e = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank,
                                                                           flags=args.flags | (_capi.F_OVERLAP_AGENTS if args.overlap else 0)),
                              **pp.engine_kwargs())
+            return e, e.iterate, e.sync, e.close
+        if mode == "p2p":
+            # peer exchange: the ranks' receive areas are mapped into each other (hipIpc handles over the host channel);
+            # the sum is one kernel of the iteration graph
+            e = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank, flags=args.flags,
+                                                                          n_agents_global=A_global), **pp.engine_kwargs())
+            hs = [None] * world
+            mine = e.xchg_export(world)
+            if world > 1:
+                dist.all_gather_object(hs, mine)
+            else:
+                hs = [mine]
+            e.xchg_init(world, rank, hs)
             return e, e.iterate, e.sync, e.close
         if mode in ("lib", "lib-graph"):
             # every rank already holds its own grid; the library joins the ranks (RCCL) and owns the all-reduce
@@ -314,26 +329,54 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return bool(flag.item())
 
+    def sums_are_right(eng):
+        """The consensus sum itself, independently of the transport: every rank adds up its own units' injections on the host,
+        the host channel (gloo) adds the ranks, and the result must be the injection every rank's device holds."""
+        P, D, C, _E = eng.get_primal()
+        loc = np.zeros((pp.N, pp.T))
+        np.add.at(loc, np.asarray(pp.gen_node, dtype=np.int64), P)
+        np.add.at(loc, np.asarray(pp.sto_node, dtype=np.int64), D - C)
+        tot = torch.tensor(loc, dtype=torch.float64, device=ctl_dev)
+        dist.all_reduce(tot)
+        want = tot.cpu().numpy() - np.asarray(pp.demand, dtype=np.float64).reshape(pp.N, pp.T)
+        got = eng.get_consensus()[0]
+        return float(np.abs(got - want).max()) <= 1e-9 * max(1.0, float(np.abs(want).max()))
+
     clock_warm()
-    comm_mode, given_up = None, []
+    comm_mode, given_up, dt = None, [], None
     for mode in modes:
-        ok, why, closer = True, "", None
+        # one transport: set-up, warm-up, checks, then the timed region; whatever goes wrong on any rank, all ranks move on
+        why, closer = "", None
         try:
             eng, step, sync, closer = set_up(mode)
             step(args.warmup)
             sync()
         except Exception as e:                      # noqa: BLE001 — whatever the transport raised
-            ok, why = False, f"{type(e).__name__}: {e}"
-        if not all_ranks(ok):
+            why = f"{type(e).__name__}: {e}"
+        if not all_ranks(not why):
             why = why or "another rank failed"
         elif world > 1:
-            # every rank must hold the same duals: they are computed redundantly from the all-reduced sums. A collective
-            # that did not run (or ran out of order) shows up here, before anything is timed.
+            # every rank must hold the same duals: they are computed redundantly from the summed vector. A sum that did
+            # not happen (or happened out of order) shows up here, before anything is timed.
             lam_here = torch.tensor(eng.get_duals()[0], dtype=torch.float64, device=ctl_dev)
             lam_all = [torch.zeros_like(lam_here) for _ in range(world)]
             dist.all_gather(lam_all, lam_here)
             if any(not torch.equal(lam_all[0], x) for x in lam_all[1:]):
-                why = f"duals differ across ranks after {args.warmup} iterations — the consensus all-reduce did not do its job"
+                why = f"duals differ across ranks after {args.warmup} iterations — the consensus sum did not do its job"
+            elif not all_ranks(sums_are_right(eng)):
+                why = "the summed injections are not the sum of the ranks' injections"
+        if not why:
+            try:
+                barrier()
+                t0 = time.perf_counter()
+                step(args.steps)
+                sync()
+                barrier()
+                dt = time.perf_counter() - t0
+            except Exception as e:                  # noqa: BLE001
+                why = f"in the timed region: {type(e).__name__}: {e}"
+            if not all_ranks(not why):
+                why = why or "another rank failed in the timed region"
         if not why:
             comm_mode = mode
             break
@@ -346,13 +389,7 @@ def main():
                 pass
     if comm_mode is None:
         raise SystemExit(f"rank {rank}: no transport worked: {given_up}")
-    use_lib_comm = comm_mode in ("lib", "lib-graph")
-    barrier()
-    t0 = time.perf_counter()
-    step(args.steps)
-    sync()
-    barrier()
-    dt = time.perf_counter() - t0
+    use_lib_comm = comm_mode in ("lib", "lib-graph", "p2p")
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -362,8 +399,10 @@ def main():
     fails = eng.solver_failures()
     if use_lib_comm:
         w_, r_, g_ = eng.comm_info()
-        comm_info = {"transport": "RCCL all-reduce issued by libdopf_hip (dopf_comm_init)", "world": w_,
-                     "captured_in_hipgraph": bool(g_)}
+        comm_info = {"transport": ("peer exchange: one kernel per iteration stores the rank's consensus vector into every peer's "
+                                   "memory and adds the copies in rank order (dopf_xchg_*)") if comm_mode == "p2p" else
+                                  "RCCL all-reduce issued by libdopf_hip (dopf_comm_init)",
+                     "mode": comm_mode, "world": w_, "captured_in_hipgraph": bool(g_)}
     elif sharded:
         comm_info = {"transport": f"torch.distributed ({args.backend}) all-reduce between dopf_local_update and dopf_apply_consensus",
                      "world": world, "captured_in_hipgraph": False}

@@ -63,7 +63,9 @@ F_COMM_HOST = 64
 F_DEBUG_ROOT_CAP = 128
 F_KEEP_DELTAS = 256
 F_COMM_GRAPH = 512
+F_COMM_P2P = 1024
 COMM_ID_BYTES = 128
+XCHG_HANDLE_BYTES = 64
 
 
 class DopfError(RuntimeError):
@@ -137,6 +139,8 @@ class CApi:
             # consensus sum across GPUs inside the library (RCCL, loaded on first use)
             self._sig("comm_unique_id", C.c_int, [C.c_void_p])
             self._sig("comm_init", C.c_int, [ctxp, C.c_int32, C.c_int32, C.c_void_p])
+            self._sig("xchg_export", C.c_int, [ctxp, C.c_int32, C.c_void_p])
+            self._sig("xchg_init", C.c_int, [ctxp, C.c_int32, C.c_int32, C.c_void_p])
             self._sig("comm_info", C.c_int, [ctxp, c_int32_p, c_int32_p, c_int32_p])
             self._sig("multi_create", C.c_int, [C.POINTER(ctxp), C.POINTER(DopfProblem), C.POINTER(DopfParams), C.c_int32, c_int32_p])
             self._sig("multi_destroy", None, [ctxp])
@@ -277,6 +281,21 @@ class Engine:
     def comm_init(self, world: int, rank: int, unique_id: bytes):
         buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
         self._chk(self.api.comm_init(self._ctx, int(world), int(rank), buf))
+
+    # -- the same sum by the peer exchange (direct stores into the peers' memory, no collective library) ----------
+    def xchg_export(self, world: int) -> bytes:
+        """Allocates this rank's receive area; 64 opaque bytes (hipIpcMemHandle_t) to gather over all ranks."""
+        buf = C.create_string_buffer(XCHG_HANDLE_BYTES)
+        self._chk(self.api.xchg_export(self._ctx, int(world), buf))
+        return buf.raw
+
+    def xchg_init(self, world: int, rank: int, handles):
+        """handles: the world handles in rank order (list of bytes or one bytes object)."""
+        blob = b"".join(handles) if not isinstance(handles, (bytes, bytearray)) else bytes(handles)
+        if len(blob) != world * XCHG_HANDLE_BYTES:
+            raise ValueError("need world x 64 bytes of handles")
+        buf = C.create_string_buffer(blob, len(blob))
+        self._chk(self.api.xchg_init(self._ctx, int(world), int(rank), buf))
 
     def comm_info(self):
         """(world, rank, collective captured in the hipGraph?)"""

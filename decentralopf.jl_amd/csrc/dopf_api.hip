@@ -119,11 +119,11 @@ void enqueue_local(dopf_ctx *c, bool single)
     launch_reduce(v, c->main);
 }
 
-void enqueue_apply(dopf_ctx *c, bool single)
+void enqueue_apply(dopf_ctx *c, bool single, const XchgView *xd)
 {
     DevView v = c->v;
     v.sliceDual = slice_dual(v, single) ? 1 : 0;
-    launch_dual(v, c->main);
+    launch_dual(v, c->main, xd);
 }
 
 void drop_graphs(dopf_ctx *c)
@@ -151,9 +151,13 @@ namespace {
 int enqueue_iteration(dopf_ctx *c)
 {
     const bool single = c->comm == nullptr;
-    enqueue_local(c, single);
-    if (!single) { const int rc = comm_enqueue_allreduce(c); if (rc) return rc; }
-    enqueue_apply(c, single);
+    // copper plate + peer exchange: the one-block dual kernel exchanges the vector itself — the single-GPU chain, no extra launch
+    const XchgView *xd = comm_xchg(c);
+    if (xd && !(c->v.L == 0 && slice_dual(c->v, true))) xd = nullptr;
+    const bool like_single = single || xd != nullptr;
+    enqueue_local(c, like_single);
+    if (!like_single) { const int rc = comm_enqueue_allreduce(c); if (rc) return rc; }
+    enqueue_apply(c, like_single, xd);
     return DOPF_OK;
 }
 
@@ -177,6 +181,8 @@ int build_graph(dopf_ctx *c, int iters, hipGraphExec_t *out)
 // a storage sub-problem that hit the root search's iteration cap leaves an unconverged row behind: report it
 int check_solver(dopf_ctx *c)
 {
+    if (c->host_st.xchg_timeout)
+        return fail(c, DOPF_E_DEVICE, "peer exchange: a rank's part of the consensus sum did not arrive in time; the state is not valid");
     if (c->host_st.solver_fail > c->solver_fail_seen) {
         const unsigned long long n = c->host_st.solver_fail - c->solver_fail_seen;
         c->solver_fail_seen = c->host_st.solver_fail;
@@ -423,7 +429,7 @@ int dopf_iterate(dopf_ctx *c, int32_t n_iters, int32_t *iters_done, int32_t *con
     // with a communicator of more than one rank the chain is launched eagerly unless the caller opts into capturing
     // the collective (DOPF_F_COMM_GRAPH): either way nothing synchronises with the host inside the loop, and the
     // host enqueues an iteration's four launches faster than the GPU retires them
-    bool eager = (c->q.flags & DOPF_F_NO_GRAPH) != 0 || (comm_world(c) > 1 && !(c->q.flags & DOPF_F_COMM_GRAPH));
+    bool eager = (c->q.flags & DOPF_F_NO_GRAPH) != 0 || (!comm_capturable(c) && !(c->q.flags & DOPF_F_COMM_GRAPH));
     if (!eager && !c->graphs_valid) {
         int rc = build_graph(c, 1, &c->graph1);
         if (rc == DOPF_OK) rc = build_graph(c, kMid, &c->graphM);

@@ -26,6 +26,7 @@
 #include <rccl/rccl.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -39,6 +40,11 @@ struct dopf_comm_state {
     ncclComm_t comm = nullptr;
     int world = 1, rank = 0;
     bool host_sum = false;      // DOPF_F_COMM_HOST: dopf_multi_iterate adds the buffers itself
+    bool p2p = false;           // peer exchange (k_xchg) instead of an RCCL collective
+    XchgView xv{};
+    void *xbuf = nullptr;       // this rank's receive area (fine-grained device memory)
+    size_t xbytes = 0;
+    std::vector<void *> opened; // IPC mappings of other processes' areas
 };
 
 namespace {
@@ -95,6 +101,11 @@ int comm_enqueue_allreduce(dopf_ctx *c)
 {
     dopf_comm_state *cs = c->comm;
     if (!cs || cs->host_sum) return DOPF_OK;       // (host transport: dopf_multi_iterate adds)
+    if (cs->p2p) {
+        if (cs->xv.world < 1) return fail(c, DOPF_E_INVALID, "peer exchange exported but not initialised (dopf_xchg_init)");
+        launch_xchg(c->v, cs->xv, c->main);
+        return DOPF_OK;
+    }
     const size_t n = (size_t)c->v.N * c->v.T + 2 * (size_t)c->v.L * c->v.T + 1;
     const ncclResult_t r = g_rccl.AllReduce(c->v.cons, c->v.cons, n, ncclDouble, ncclSum, cs->comm, c->main);
     if (r != ncclSuccess) return fail(c, DOPF_E_DEVICE, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
@@ -103,10 +114,18 @@ int comm_enqueue_allreduce(dopf_ctx *c)
 
 int comm_world(const dopf_ctx *c) { return c->comm ? c->comm->world : 1; }
 
+const XchgView *comm_xchg(const dopf_ctx *c) { return (c->comm && c->comm->p2p && c->comm->xv.world > 0) ? &c->comm->xv : nullptr; }
+
+// a chain with an RCCL collective of more than one rank is launched eagerly unless the caller opts into capturing it;
+// the peer exchange is an ordinary kernel and is always captured
+bool comm_capturable(const dopf_ctx *c) { return !c->comm || c->comm->p2p || c->comm->host_sum || c->comm->world == 1; }
+
 void comm_release(dopf_ctx *c)
 {
     if (!c->comm) return;
     if (c->comm->comm && g_rccl.lib) g_rccl.CommDestroy(c->comm->comm);
+    for (void *p : c->comm->opened) hipIpcCloseMemHandle(p);
+    if (c->comm->xbuf) hipFree(c->comm->xbuf);
     delete c->comm;
     c->comm = nullptr;
 }
@@ -153,9 +172,112 @@ int for_each_shard(dopf_multi *m, F f)
     return DOPF_OK;
 }
 
+// ---- peer exchange set-up -------------------------------------------------------------------------------------
+// layout of a rank's receive area: [world] hello words | [2][world][chunks] flags | (256-byte aligned) [2][world][n] doubles
+struct XchgLayout {
+    size_t n, nchunks, flags_off, data_off, bytes;
+    XchgLayout(size_t n_, int world) : n(n_), nchunks((n_ + kXchgChunk - 1) / kXchgChunk)
+    {
+        flags_off = (size_t)kXchgMaxWorld * sizeof(unsigned long long);
+        data_off = (flags_off + 2 * (size_t)world * nchunks * sizeof(unsigned long long) + 255) / 256 * 256;
+        bytes = data_off + 2 * (size_t)world * n * sizeof(double);
+    }
+};
+
+unsigned long long xchg_timeout_ticks()
+{
+    double ms = 20000.0;                            // generous: ranks reach their first iteration seconds apart
+    if (const char *e = getenv("DOPF_XCHG_TIMEOUT_MS")) ms = atof(e);
+    return (unsigned long long)(ms * 1e5);          // wall_clock64: 100 MHz
+}
+
+int xchg_alloc(dopf_ctx *c, dopf_comm_state *cs, int world)
+{
+    const XchgLayout lay((size_t)dopf_consensus_size(c), world);
+    cs->xbytes = lay.bytes;
+    // fine-grained: stores of other devices become visible to this device's loads without cache maintenance on this side
+    HIPCHK(c, hipExtMallocWithFlags(&cs->xbuf, lay.bytes, hipDeviceMallocFinegrained));
+    HIPCHK(c, hipMemset(cs->xbuf, 0, lay.bytes));
+    HIPCHK(c, hipDeviceSynchronize());
+    return DOPF_OK;
+}
+
+void xchg_fill_view(dopf_ctx *c, dopf_comm_state *cs, int world, int rank, void *const *areas)
+{
+    const XchgLayout lay((size_t)dopf_consensus_size(c), world);
+    XchgView &x = cs->xv;
+    x.world = world; x.me = rank; x.nchunks = (int)lay.nchunks; x.n = lay.n; x.timeout_ticks = xchg_timeout_ticks();
+    for (int r = 0; r < world; ++r) {
+        x.flags[r] = reinterpret_cast<unsigned long long *>((char *)areas[r] + lay.flags_off);
+        x.data[r] = reinterpret_cast<double *>((char *)areas[r] + lay.data_off);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int dopf_xchg_export(dopf_ctx *c, int32_t world, void *handle64)
+{
+    if (!c || !handle64 || world < 1 || world > kXchgMaxWorld) return fail(c, DOPF_E_INVALID, "bad argument (world <= %d)", kXchgMaxWorld);
+    if (c->comm) return fail(c, DOPF_E_INVALID, "context already has a communicator");
+    DeviceGuard guard(c->device);
+    dopf_comm_state *cs = new (std::nothrow) dopf_comm_state;
+    if (!cs) return fail(c, DOPF_E_NOMEM, "out of host memory");
+    cs->world = world; cs->p2p = true;
+    int rc = xchg_alloc(c, cs, world);
+    if (rc == DOPF_OK) {
+        hipIpcMemHandle_t h;
+        static_assert(sizeof h == DOPF_XCHG_HANDLE_BYTES, "hipIpcMemHandle_t size");
+        const hipError_t e = hipIpcGetMemHandle(&h, cs->xbuf);
+        if (e != hipSuccess) rc = fail(c, DOPF_E_DEVICE, "hipIpcGetMemHandle: %s", hipGetErrorString(e));
+        else memcpy(handle64, &h, sizeof h);
+    }
+    if (rc) { if (cs->xbuf) hipFree(cs->xbuf); delete cs; return rc; }
+    c->comm = cs;               // not usable before dopf_xchg_init (world of the view is 0 until then)
+    return DOPF_OK;
+}
+
+int dopf_xchg_init(dopf_ctx *c, int32_t world, int32_t rank, const void *handles)
+{
+    if (!c || !handles || !c->comm || !c->comm->p2p || c->comm->world != world || rank < 0 || rank >= world || c->comm->xv.world)
+        return fail(c, DOPF_E_INVALID, "bad argument (dopf_xchg_export first, same world)");
+    DeviceGuard guard(c->device);
+    dopf_comm_state *cs = c->comm;
+    cs->rank = rank;
+    void *areas[kXchgMaxWorld] = {nullptr};
+    for (int r = 0; r < world; ++r) {
+        if (r == rank) { areas[r] = cs->xbuf; continue; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char *)handles + (size_t)r * DOPF_XCHG_HANDLE_BYTES, sizeof h);
+        void *p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return fail(c, DOPF_E_DEVICE, "hipIpcOpenMemHandle (rank %d): %s", r, hipGetErrorString(e));
+        cs->opened.push_back(p);
+        areas[r] = p;
+    }
+    xchg_fill_view(c, cs, world, rank, areas);
+    // rendezvous: say hello in every peer's area, wait until every peer has said hello here — from then on all areas
+    // are mapped everywhere and the ranks are at most a host call apart
+    const unsigned long long one = 1ull;
+    for (int r = 0; r < world; ++r)
+        HIPCHK(c, hipMemcpy((char *)areas[r] + (size_t)rank * sizeof one, &one, sizeof one, hipMemcpyHostToDevice));
+    double wait_s = 120.0;
+    if (const char *e = getenv("DOPF_XCHG_HELLO_S")) wait_s = atof(e);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        unsigned long long hello[kXchgMaxWorld];
+        HIPCHK(c, hipMemcpy(hello, cs->xbuf, sizeof hello, hipMemcpyDeviceToHost));
+        int seen = 0;
+        for (int r = 0; r < world; ++r) seen += hello[r] == 1ull;
+        if (seen == world) break;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_s)
+            return fail(c, DOPF_E_DEVICE, "peer exchange: %d of %d ranks showed up within %.0f s", seen, world, wait_s);
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    drop_graphs(c);
+    return DOPF_OK;
+}
 
 int dopf_comm_unique_id(void *id128)
 {
@@ -213,18 +335,20 @@ int dopf_multi_create(dopf_multi **out, const dopf_problem *p, const dopf_params
     if (!out || !p || !q || n_gpus < 1) return mfail(nullptr, DOPF_E_INVALID, "bad argument");
     *out = nullptr;
     const bool host_sum = (q->flags & DOPF_F_COMM_HOST) != 0;
+    const bool p2p = !host_sum && (q->flags & DOPF_F_COMM_P2P) != 0;
+    if (p2p && n_gpus > kXchgMaxWorld) return mfail(nullptr, DOPF_E_INVALID, "peer exchange: too many shards");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return mfail(nullptr, DOPF_E_DEVICE, "no HIP device; libdopf_hip has no CPU fallback");
     std::vector<int> dev(n_gpus);
     for (int i = 0; i < n_gpus; ++i) {
         dev[i] = devices ? devices[i] : (host_sum ? i % ndev : i);
         if (dev[i] < 0 || dev[i] >= ndev) return mfail(nullptr, DOPF_E_INVALID, "device ordinal out of range (n_gpus exceeds the visible devices?)");
-        if (!host_sum)
+        if (!host_sum && !p2p)
             for (int j = 0; j < i; ++j)
                 if (dev[j] == dev[i]) return mfail(nullptr, DOPF_E_INVALID, "RCCL needs one distinct device per shard (DOPF_F_COMM_HOST lifts this for tests)");
     }
     const Rccl *r = nullptr;
-    if (!host_sum && n_gpus > 1) {
+    if (!host_sum && !p2p && n_gpus > 1) {
         r = rccl();
         if (!r) return mfail(nullptr, DOPF_E_DEVICE, g_rccl.err);
     }
@@ -260,7 +384,34 @@ int dopf_multi_create(dopf_multi **out, const dopf_problem *p, const dopf_params
             return rc;
         }
     }
-    if (n_gpus > 1 || host_sum) {
+    if (p2p) {
+        // every shard's receive area is directly addressable from every other shard's device
+        void *areas[kXchgMaxWorld] = {nullptr};
+        for (int i = 0; i < n_gpus; ++i) {
+            dopf_ctx *c = m->ctx[i];
+            DeviceGuard guard(c->device);
+            dopf_comm_state *cs = new dopf_comm_state;
+            cs->world = n_gpus; cs->rank = i; cs->p2p = true;
+            c->comm = cs;
+            int rc = xchg_alloc(c, cs, n_gpus);
+            for (int j = 0; j < n_gpus && rc == DOPF_OK; ++j) {
+                if (dev[j] == dev[i]) continue;
+                int can = 0;
+                hipDeviceCanAccessPeer(&can, dev[i], dev[j]);
+                if (!can) { rc = fail(c, DOPF_E_DEVICE, "device %d cannot address device %d", dev[i], dev[j]); break; }
+                const hipError_t e = hipDeviceEnablePeerAccess(dev[j], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) rc = fail(c, DOPF_E_DEVICE, "hipDeviceEnablePeerAccess: %s", hipGetErrorString(e));
+                (void)hipGetLastError();
+            }
+            if (rc) {
+                snprintf(g_multi_err, 512, "shard %d: %s", i, dopf_last_error(c));
+                dopf_multi_destroy(m);
+                return rc;
+            }
+            areas[i] = cs->xbuf;
+        }
+        for (int i = 0; i < n_gpus; ++i) xchg_fill_view(m->ctx[i], m->ctx[i]->comm, n_gpus, i, areas);
+    } else if (n_gpus > 1 || host_sum) {
         std::vector<ncclComm_t> comms(n_gpus, nullptr);
         if (!host_sum) {
             const ncclResult_t e = r->CommInitAll(comms.data(), n_gpus, dev.data());

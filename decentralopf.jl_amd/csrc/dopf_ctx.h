@@ -31,13 +31,15 @@ namespace dopf {
 
 int fail(dopf_ctx *c, int code, const char *fmt, ...);
 void enqueue_local(dopf_ctx *c, bool single);
-void enqueue_apply(dopf_ctx *c, bool single);
+void enqueue_apply(dopf_ctx *c, bool single, const XchgView *xd = nullptr);
 void drop_graphs(dopf_ctx *c);
 int read_status(dopf_ctx *c);
 // dopf_comm.hip
 int comm_enqueue_allreduce(dopf_ctx *c);      // sum of the consensus buffer over the ranks, on the context's stream
 void comm_release(dopf_ctx *c);
 int comm_world(const dopf_ctx *c);             // ranks of the context's communicator (1 without one)
+const XchgView *comm_xchg(const dopf_ctx *c);   // the initialised peer exchange of the context, or null
+bool comm_capturable(const dopf_ctx *c);      // the chain incl. its consensus sum may go into a hipGraph by default
 
 struct DeviceGuard {
     int prev = -1;

@@ -39,6 +39,7 @@ struct Status {
     unsigned long long resbits[3];   // running max of |dual change| as bit patterns (>= 0 doubles)
     double res[3];          // lambda / mu / rho residual inf-norms of the last checked iteration
     double total_cost;
+    int xchg_timeout;       // peer exchange: a peer's part of the consensus sum did not arrive in time (sticky)
 };
 
 struct DevView {
@@ -132,7 +133,21 @@ int debug_timeline(unsigned long long *out, int n);     // DOPF_STATS builds: pe
 void launch_tables(const DevView &v, hipStream_t s);
 void launch_slack(const DevView &v, hipStream_t s);
 void launch_reduce(const DevView &v, hipStream_t s);
-void launch_dual(const DevView &v, hipStream_t s);      // consensus -> duals, residuals, prices, status
+// Peer exchange (dopf_comm.hip sets it up): every rank owns a receive area [2 parities][world source ranks][n doubles] plus
+// flags [2][world][chunks]; data[r] / flags[r] are rank r's areas as addressable from THIS device (own allocation, a peer
+// device of the same process, or an IPC mapping of another process's allocation).
+constexpr int kXchgMaxWorld = 16;
+constexpr int kXchgChunk = 2048;                // doubles per block
+struct XchgView {
+    int world, me, nchunks;
+    unsigned long long n;                       // doubles in the consensus vector
+    unsigned long long timeout_ticks;           // wall_clock64 ticks (100 MHz) a block waits for its peers
+    double *data[kXchgMaxWorld];
+    unsigned long long *flags[kXchgMaxWorld];
+};
+void launch_xchg(const DevView &v, const XchgView &x, hipStream_t s);   // cons <- sum over ranks of cons (rank order)
+void launch_dual(const DevView &v, hipStream_t s, const XchgView *xd = nullptr);   // xd: peer exchange inside the one-block kernel
+//      // consensus -> duals, residuals, prices, status
 void launch_derive(const DevView &v, hipStream_t s, bool from_primal);   // consensus -> inj/s/flow/price (no dual step)
 
 }  // namespace dopf

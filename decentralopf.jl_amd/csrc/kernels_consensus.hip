@@ -572,6 +572,82 @@ void launch_reduce(const DevView &v, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------
+// peer exchange: the sum of the consensus vector over the ranks WITHOUT a collective library. Every block owns a chunk of
+// the vector: it stores its rank's chunk into slot [parity][me] of EVERY rank's receive area (plain stores over xGMI for
+// the peers), publishes a sequence number per (source rank, chunk) behind a system-scope release, waits until the same
+// chunk of every rank has arrived in its own area, and adds the world copies in RANK ORDER — every rank adds the same
+// numbers in the same order, so the sums (and the duals computed from them) are bitwise identical everywhere.
+//   * no block waits before it has sent, and a block waits only for remote blocks of its own chunk: no deadlock, whatever
+//     the order blocks run in on any device;
+//   * two parities: a rank that is writing iteration k+2 into a slot has received iteration k+1 from everybody, and a
+//     rank sends k+1 only after it has consumed k (same stream) — two slots suffice; sequence numbers only grow;
+//   * a wait is bounded (wall clock): a lost peer sets Status.xchg_timeout, later exchanges do not wait again, the host
+//     reports DOPF_E_DEVICE. The kernel always ends.
+// Latency: one kernel, one xGMI store + one flag round trip (a few microseconds) against the 20-30 us of a library
+// all-reduce for the sub-kilobyte vector of a copper plate (776 B on config2).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_xchg(DevView v, XchgView x)
+{
+    if (v.st->halt) return;
+    __shared__ int bad;
+    const int tid = threadIdx.x, W = x.world, me = x.me, chunk = blockIdx.x;
+    const unsigned long long seq = (unsigned long long)v.st->iters_total + 1ull;
+    const size_t par = (size_t)(seq & 1ull), n = x.n, j0 = (size_t)chunk * kXchgChunk;
+    constexpr int U = kXchgChunk / 256;
+    if (tid == 0) bad = 0;
+    double own[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t j = j0 + tid + 256 * (size_t)u;
+        own[u] = j < n ? v.cons[j] : 0.0;
+    }
+    for (int q = 0; q < W; ++q) {
+        const int r = (me + 1 + q) % W;                    // the peers first, the own slot last
+        double *dst = x.data[r] + (par * W + me) * n;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t j = j0 + tid + 256 * (size_t)u;
+            if (j < n) dst[j] = own[u];
+        }
+    }
+    __threadfence_system();                                // this thread's stores have left for their destinations
+    __syncthreads();
+    if (tid < W)
+        __hip_atomic_store(x.flags[tid] + (par * W + me) * x.nchunks + chunk, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid < W) {
+        const unsigned long long *f = x.flags[me] + (par * W + tid) * x.nchunks + chunk;
+        const unsigned long long t0 = wall_clock64();
+        bool ok = v.st->xchg_timeout == 0;
+        while (ok && __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > x.timeout_ticks) ok = false;
+        }
+        if (!ok) atomicOr(&bad, 1);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");          // every wave: nothing older than the flags is read below
+    if (bad) {
+        if (tid == 0) v.st->xchg_timeout = 1;
+        return;
+    }
+    const double *mine = x.data[me] + par * W * n;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t j = j0 + tid + 256 * (size_t)u;
+        if (j < n) {
+            double sum = mine[j];
+            for (int r = 1; r < W; ++r) sum += mine[(size_t)r * n + j];
+            v.cons[j] = sum;
+        }
+    }
+}
+
+void launch_xchg(const DevView &v, const XchgView &x, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_xchg, dim3(x.nchunks), dim3(256), 0, s, v, x);
+}
+
+// ------------------------------------------------------------------------------------------------
 // dual update
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void atomic_max_pos(unsigned long long *addr, double vpos)
@@ -903,8 +979,11 @@ __global__ __launch_bounds__(256) void k_price_t(DevView v)
 
 // dual step + prices + stop test in ONE block when the consensus state is small (every copper-plate case):
 // saves a launch per iteration, which is what the small configurations are bound by
-template <bool UPDATE>
-__global__ __launch_bounds__(256) void k_dual_price_small(DevView v)
+// XCHG (copper plate, peer exchange): the sum over the ranks happens HERE, between the slice sums and the dual step —
+// the rank's vector goes from registers into every peer's receive area, the copies come back from the own area; no
+// launch is added to the single-GPU chain (protocol: see k_xchg).
+template <bool UPDATE, bool XCHG>
+__global__ __launch_bounds__(256) void k_dual_price_small(DevView v, XchgView x)
 {
     if (UPDATE && v.st->halt) return;
     __shared__ double red[8][256];
@@ -943,20 +1022,62 @@ __global__ __launch_bounds__(256) void k_dual_price_small(DevView v)
 #pragma unroll
         for (int c = 0; c < 8; ++c) red[c][tid] = sc[c];
         __syncthreads();
+        double tot = 0.0;
         if (me < NT) {
             const int c = (int)(me >> 5), t5 = (int)(me & 31);
-            double tot = 0.0;
             for (int q = 0; q < R; ++q) tot += red[c][q * 32 + t5];
-            v.cons[me] = tot;
-            const double x = tot - dem;                       // results.jl:58-100
-            v.inj[me] = x;
-            injL[me] = x;
         }
         double ctot = cslice;                                 // cost slices: butterfly in wave 0 (a fixed order too)
-        if (tid < 64) {
+        if (tid < 64)
             for (int d = 32; d > 0; d >>= 1) ctot += __shfl_xor(ctot, d);
-            if (tid == 0) { v.cons[NT] = ctot; v.st->total_cost = ctot; }
+        if (XCHG) {
+            __shared__ int bad;
+            const int W = x.world, rk = x.me;
+            const unsigned long long seq = (unsigned long long)v.st->iters_total + 1ull;
+            const size_t par = (size_t)(seq & 1ull), n = x.n;          // n = NT + 1: injections | cost
+            if (tid == 0) bad = 0;
+            for (int q = 0; q < W; ++q) {
+                const int r = (rk + 1 + q) % W;
+                double *dst = x.data[r] + (par * W + rk) * n;
+                if (me < NT) dst[me] = tot;
+                if (tid == 0) dst[NT] = ctot;
+            }
+            __threadfence_system();
+            __syncthreads();
+            if (tid < W) {
+                __hip_atomic_store(x.flags[tid] + (par * W + rk) * x.nchunks, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned long long *f = x.flags[rk] + (par * W + tid) * x.nchunks;
+                const unsigned long long t0 = wall_clock64();
+                bool ok = v.st->xchg_timeout == 0;
+                while (ok && __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (wall_clock64() - t0 > x.timeout_ticks) ok = false;
+                }
+                if (!ok) atomicOr(&bad, 1);
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            if (bad) {
+                if (tid == 0) v.st->xchg_timeout = 1;
+                return;
+            }
+            const double *mine = x.data[rk] + par * W * n;
+            if (me < NT) {
+                tot = mine[me];
+                for (int r = 1; r < W; ++r) tot += mine[(size_t)r * n + me];
+            }
+            if (tid == 0) {
+                ctot = mine[NT];
+                for (int r = 1; r < W; ++r) ctot += mine[(size_t)r * n + NT];
+            }
         }
+        if (me < NT) {
+            v.cons[me] = tot;
+            const double xi = tot - dem;                      // results.jl:58-100
+            v.inj[me] = xi;
+            injL[me] = xi;
+        }
+        if (tid == 0) { v.cons[NT] = ctot; v.st->total_cost = ctot; }
         __syncthreads();
         double rl = 0.0;
         if (tid < T) {
@@ -1056,12 +1177,13 @@ __global__ __launch_bounds__(256) void k_dual_price_small(DevView v)
     }
 }
 
-void launch_dual(const DevView &v, hipStream_t s)
+void launch_dual(const DevView &v, hipStream_t s, const XchgView *xd)
 {
     const size_t NT = (size_t)v.N * v.T, LT = (size_t)v.L * v.T;
     const size_t n1 = NT > LT ? NT : LT;
     if (n1 <= kSmallConsensus) {
-        hipLaunchKernelGGL(k_dual_price_small<true>, dim3(1), dim3(256), 0, s, v);
+        if (xd) hipLaunchKernelGGL((k_dual_price_small<true, true>), dim3(1), dim3(256), 0, s, v, *xd);
+        else hipLaunchKernelGGL((k_dual_price_small<true, false>), dim3(1), dim3(256), 0, s, v, XchgView{});
         return;
     }
     if ((size_t)std::max(v.N, 3 * v.L) * sizeof(double) <= 48 * 1024) {
@@ -1112,7 +1234,7 @@ void launch_derive(const DevView &v, hipStream_t s, bool from_primal)
             hipLaunchKernelGGL(k_derive_items, dim3(v.nGenItems + v.nStoItems), dim3(256), 0, s, v);
     }
     if (n1 <= kSmallConsensus) {
-        hipLaunchKernelGGL(k_dual_price_small<false>, dim3(1), dim3(256), 0, s, v);
+        hipLaunchKernelGGL((k_dual_price_small<false, false>), dim3(1), dim3(256), 0, s, v, XchgView{});
         return;
     }
     if ((size_t)std::max(v.N, 3 * v.L) * sizeof(double) <= 48 * 1024) {

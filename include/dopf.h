@@ -111,6 +111,7 @@ typedef struct dopf_params {
 #define DOPF_F_COMM_GRAPH   512  /* contexts joined to a communicator of > 1 ranks: capture the RCCL all-reduce into the iteration
                                    hipGraphs instead of launching the chain eagerly (default: eager — the host enqueues an
                                    iteration faster than the GPU retires it, and plain launches are RCCL's best-trodden path) */
+#define DOPF_F_COMM_P2P    1024  /* dopf_multi_*: the consensus sum by the peer exchange (dopf_xchg_* below) instead of RCCL */
 #define DOPF_F_DEBUG_ROOT_CAP 128 /* tests: the scan kernel's root search gives up after 2 iterations instead of
                                    80, so that the DOPF_E_SOLVER path can be exercised                        */
 
@@ -231,6 +232,19 @@ int dopf_comm_init(dopf_ctx *ctx, int32_t world, int32_t rank, const void *id128
 /* world / rank of the context's communicator (1 / 0 without one); in_graph = 1 once dopf_iterate has
  * captured the collective into its graphs, 0 while it launches eagerly. Any pointer may be NULL. */
 int dopf_comm_info(const dopf_ctx *ctx, int32_t *world, int32_t *rank, int32_t *in_graph);
+
+/* ---- peer exchange: the same sum without a collective library ------------------------------------------------
+ * For the sub-kilobyte consensus vector of a copper plate (776 B on BASELINE configs[2]) a library all-reduce is pure
+ * latency (tens of microseconds against a 40 us iteration). Here ONE kernel per iteration stores this rank's vector
+ * into every peer's receive area over xGMI, publishes a sequence number, waits for the peers' numbers and adds the
+ * copies in rank order (bitwise identical sums on every rank; csrc/kernels_consensus.hip k_xchg). The kernel is part of
+ * the iteration hipGraphs. One process per GPU: every rank calls dopf_xchg_export (allocates its receive area, returns
+ * a 64-byte hipIpc handle), the world handles are gathered in rank order over any host channel, every rank calls
+ * dopf_xchg_init (maps the peers' areas, host rendezvous). world <= 16. A peer that does not show up within
+ * DOPF_XCHG_TIMEOUT_MS (default 20 000) makes dopf_iterate / dopf_sync return DOPF_E_DEVICE; the kernels always end. */
+#define DOPF_XCHG_HANDLE_BYTES 64
+int dopf_xchg_export(dopf_ctx *ctx, int32_t world, void *handle64);
+int dopf_xchg_init(dopf_ctx *ctx, int32_t world, int32_t rank, const void *handles /* world x 64 bytes, rank order */);
 
 /* One process, n GPUs — what a Julia `ccall` host uses (no launcher): p holds ALL agents; the library
  * cuts the agent lists into n contiguous shards, creates one context per device (devices[i], or 0..n-1
