@@ -122,13 +122,17 @@ function dopf_check_multi(rc::Cint, m::Ptr{Cvoid})
     error("libdopf_hip error $rc: $msg")
 end
 
+const DOPF_F_COMM_P2P = 1024      # include/dopf.h
+
 """
     ADMM(gamma, nodes, generators, storages, lines; max_iters=0, n_gpus=1, record=false, ...)
 
 The reference's constructor (src/structures/admm.jl:23-27) with the same five positional arguments. The `Int`
 struct fields are promoted to Float64 when packed; matrices go over column-major, as Julia stores them.
 Keywords are additions: `max_iters` (the reference loops forever on a divergent case), `n_gpus` (> 1: agents are
-sharded over that many devices inside the library, one RCCL all-reduce per iteration), `record`, and the
+sharded over that many devices inside the library, one RCCL all-reduce per iteration — or, with
+`flags = DOPF_F_COMM_P2P`, the library's peer exchange: direct stores into the other devices' memory, no collective
+library, a few microseconds instead of tens for the small vector of a copper plate), `record`, and the
 reference's literals `w_flow = 10`, `w_prox = 1`, `eps = 1e-3`, `mask_thr = 1e-2`.
 """
 function ADMM(gamma::Float64, nodes::Vector{Node}, generators::Vector{Generator}, storages::Vector{Storage},
