@@ -310,9 +310,14 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         // the storage blocks and ~1536 somewhat larger ones come out ahead (measured on config2: 25.7 -> 24.0 us)
         int target_items = v.fuseAgents ? 1536 : 2048;
         if (const char *e = getenv("DOPF_GEN_TARGET_ITEMS")) target_items = std::max(1, atoi(e));     // (experiments)
+        // streaming generator blocks (fused launch, one node): an item is ONE batch of loads, <= kGenStreamRows rows per lane
+        const bool stream = v.fuseAgents && N == 1 && !getenv("DOPF_NO_GEN_STREAM");
+        if (stream) target_items = std::max(target_items, (G + kGenStreamRows * R - 1) / (kGenStreamRows * R));
         int chunk = std::max(R, (G + target_items - 1) / target_items);
         chunk = (chunk + R - 1) / R * R;
+        if (stream) chunk = std::min(chunk, kGenStreamRows * R);
         make_items(gnode, N, chunk, gitems, ngb, ngib);
+        v.genChunk = N == 1 ? chunk : 0;
         // (on short blocks the skip test costs more than the rows it saves: measured on config1/config2)
         v.genSkip = (v.genTT2 > 0 && chunk >= 8 * R && !(q->flags & DOPF_F_NO_ROW_SKIP)) ? 1 : 0;
         const int NG = S > 0 ? 256 / lc.stoLPS : 1;
@@ -324,6 +329,14 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     for (int n = 0; n < N; ++n) v.maxNodeAgents = std::max(v.maxNodeAgents, (ngb[n + 1] - ngb[n]) + (nsb[n + 1] - nsb[n]));
     v.nGenItems = (int)gitems.size();
     v.nStoItems = (int)sitems.size();
+    v.genBlocks = 0;
+    if (v.fuseAgents && v.genChunk > 0 && !v.genSkip && v.genChunk <= kGenStreamRows * v.genR2 && !getenv("DOPF_NO_GEN_STREAM")) {
+        // as many generator blocks as find a wave slot next to the storage blocks (3 blocks of 256 per CU at the fused
+        // kernel's register count): all resident from the start; at least a quarter of the chip
+        int nb = 3 * 256 - v.nStoItems;
+        if (const char *e = getenv("DOPF_GEN_BLOCKS")) nb = atoi(e);          // (experiments)
+        v.genBlocks = std::min(v.nGenItems, std::max(nb, 192));
+    }
     {
         // level-1 reduce blocks per node: ~16 items per block, at most 64 (and N*RB blocks in total)
         int max_items = 1;
@@ -342,6 +355,13 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     }
     TRY(dev_upload(c, &v.fmax, std::vector<double>(p->f_max, p->f_max + L)));
     TRY(dev_upload(c, &v.gen_mc, gmc)); TRY(dev_upload(c, &v.gen_pmax, gpm));
+    {
+        std::vector<double> mp(2 * (size_t)G);
+        for (int i = 0; i < G; ++i) { mp[2 * (size_t)i] = gmc[i]; mp[2 * (size_t)i + 1] = gpm[i]; }
+        const double *d = nullptr;
+        TRY(dev_upload(c, &d, mp));
+        v.gen_mp = reinterpret_cast<const double2 *>(d);
+    }
     TRY(dev_upload(c, &v.sto_mc, smc)); TRY(dev_upload(c, &v.sto_pmax, spm)); TRY(dev_upload(c, &v.sto_emax, sem));
     TRY(dev_upload(c, &v.gen_items, gitems)); TRY(dev_upload(c, &v.sto_items, sitems));
     TRY(dev_upload(c, &v.node_gen_beg, ngb)); TRY(dev_upload(c, &v.node_sto_beg, nsb));

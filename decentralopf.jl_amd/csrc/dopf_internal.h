@@ -47,6 +47,8 @@ struct DevView {
     int maxNodeAgents;              // most agents (generators + storages) at one node
     int nGenItems, nStoItems;
     int genTT, genR;                // generator block tiling: TT = min(T, 512) timesteps x R agents
+    int genBlocks;                  // > 0 (needs genChunk): the fused launch has this many generator blocks, each walking items b, b + genBlocks, ...
+    int genChunk;                   // > 0: one node, generator item i = rows [i*genChunk, (i+1)*genChunk) (no item look-up)
     int genSkip;                    // pair kernel with row skipping (blocks sweep >= 8 passes of agents)
     int genTT2, genR2;              // pair kernel (copper plate, even T <= 1024): T/2 double2 columns x R2 agents; 0 = off
     int sliceDual;                  // per launch: k_reduce stops after the slice sums (level 1) and the one-block dual
@@ -62,6 +64,7 @@ struct DevView {
     const double *demand, *ptdf, *fmax;
     const double *ptdfT;                            // [n + N*l]: the transpose, for the price kernel's node-major threads
     const double *gen_mc, *gen_pmax;
+    const double2 *gen_mp;                          // [g] {mc, pmax} side by side: one 16-byte load per row (streaming blocks)
     const double *sto_mc, *sto_pmax, *sto_emax;
     const Item *gen_items, *sto_items;
     const int *node_gen_beg, *node_sto_beg;         // N+1 each: agent ranges per node
@@ -98,6 +101,7 @@ struct DevView {
 
 // consensus states up to this many (n,t) / (l,t) entries take the one-block dual step
 constexpr size_t kSmallConsensus = 4096;
+constexpr int kGenStreamRows = 6;          // rows per lane and item in the streaming generator blocks (one batch of loads)
 
 struct Launch {
     int stoLPS, stoNCH;

@@ -15,8 +15,10 @@
 
 namespace dopf {
 
-#ifdef DOPF_STATS
+#if defined(DOPF_STATS) || defined(DOPF_BLOCK_STAMPS)
 __device__ unsigned long long g_timeline[8192 * 8 + 8192 * 8];      // per wave of the storage body: wall-clock stamps (100 MHz)
+#endif
+#ifdef DOPF_STATS
 #define DOPF_STAMP(i) { if (lane == 0 && rep == 0 && round == 0) { const int w_ = blk * 4 + (tid >> 6); if (w_ < 8192) g_timeline[w_ * 8 + (i)] = wall_clock64(); } }
 #else
 #define DOPF_STAMP(i)
@@ -146,13 +148,48 @@ __global__ __launch_bounds__(512) void k_gen_update(DevView v)
     if (tid == 0) v.part_gcost[blockIdx.x] = red[0];
 }
 
+// End of a generator block of the pair kernels: per-column sums of the R agent lanes and the block's cost, every sum in
+// a fixed order (cost: butterfly inside each wave, then the waves in order), ONE barrier — a block lives for a few
+// microseconds and a barrier per tree level was a quarter of that.
+// LDS_ONLY: the barrier waits for this wave's LDS traffic only. __syncthreads() also drains every global load in
+// flight (s_waitcnt vmcnt(0)) — in the streaming blocks those are the NEXT item's rows, i.e. exactly the overlap the
+// streaming is for. Only LDS data crosses this barrier.
+template <int BS, bool LDS_ONLY = false>
+__device__ __forceinline__ void gen_pair_sums(const DevView &v, const int blk, const int tid, const int r, const int tt,
+                                              double acc0, double acc1, double cost, double (*red)[BS], double *wc)
+{
+    const int T = v.T, TT = v.genTT2, R = v.genR2;
+    for (int d = 32; d > 0; d >>= 1) cost += __shfl_xor(cost, d);
+    red[0][tid] = acc0; red[1][tid] = acc1;
+    if ((tid & 63) == 0) wc[tid >> 6] = cost;
+    if (LDS_ONLY) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+    if (r == 0 && tt < TT) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int q = 0; q < R; ++q) { s0 += red[0][q * TT + tt]; s1 += red[1][q * TT + tt]; }
+        v.part_ginj[(size_t)blk * T + 2 * tt] = s0;
+        v.part_ginj[(size_t)blk * T + 2 * tt + 1] = s1;
+    }
+    if (tid == 0) {
+        double c = 0.0;
+        for (int q = 0; q < BS / 64; ++q) c += wc[q];
+        v.part_gcost[blk] = c;
+    }
+}
+
 // Copper plate, even T: each thread owns TWO consecutive timesteps of an agent, so every P access is a
 // 16-byte-per-lane double2 (the widest coalesced form), half as many load/store instructions per byte.
-template <int BS>
+template <int BS, bool CHECK_HALT = false>
 __device__ __forceinline__ void gen_pair_body(const DevView &v, const int blk)
 {
+    const int halt = CHECK_HALT ? v.st->halt : 0;        // (the load is in flight with the ones below)
     __shared__ double red[2][BS];
-    const Item it = v.gen_items[blk];
+    __shared__ double wc[BS / 64];
+    // one node (every copper plate of BASELINE.json): the items are equal cuts of the generator list — no table look-up
+    // between the block's start and its first row loads
+    Item it;
+    if (v.genChunk > 0) { it.a0 = blk * v.genChunk; it.a1 = min(v.G, it.a0 + v.genChunk); it.node = 0; }
+    else it = v.gen_items[blk];
     const int T = v.T, N = v.N, TT = v.genTT2, R = v.genR2;     // TT = T/2 pair columns
     const int tid = threadIdx.x;
     const int r = tid / TT, tt = tid - r * TT;
@@ -168,10 +205,8 @@ __device__ __forceinline__ void gen_pair_body(const DevView &v, const int blk)
         // rows in batches of GU: every load of the batch is issued before the first store (the compiler may not move a
         // load across a store to the same array on its own), so a block keeps GU x 16 B per lane in flight — what lets the
         // generator blocks of the fused launch stream while the storage blocks hold most of the wave slots
-#ifndef DOPF_GU
-#define DOPF_GU 4
-#endif
-        constexpr int GU = DOPF_GU;
+        // (the fused launch cuts config2's generators into items of 6 rows per lane: one batch)
+        constexpr int GU = BS == 256 ? 6 : 4;
         for (int g0 = it.a0 + r; g0 < it.a1; g0 += GU * R) {
             double2 p0[GU];
             double mc[GU], pm[GU];
@@ -195,22 +230,89 @@ __device__ __forceinline__ void gen_pair_body(const DevView &v, const int blk)
             }
         }
     }
-    red[0][tid] = acc0; red[1][tid] = acc1;
-    __syncthreads();
-    if (r == 0 && tt < TT) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int q = 0; q < R; ++q) { s0 += red[0][q * TT + tt]; s1 += red[1][q * TT + tt]; }
-        v.part_ginj[(size_t)blk * T + 2 * tt] = s0;
-        v.part_ginj[(size_t)blk * T + 2 * tt + 1] = s1;
+    if (CHECK_HALT && halt) return;
+    gen_pair_sums<BS>(v, blk, tid, r, tt, acc0, acc1, cost, red, wc);
+}
+
+// Generator blocks of the fused launch (one node, items = equal cuts of <= GU rows per lane): a block STAYS and walks the
+// items first, first + stride, ... with the next item's rows already on their way while the current one is computed,
+// stored and summed. While the storage blocks hold most of the wave slots only ~200 generator blocks are resident:
+// launched one per item each of them spent 3.7 us mostly waiting on its one batch of loads (390 of 1516 items done
+// when the storage blocks retired, 2.5 TB/s); streaming, the same 200 blocks keep two batches in flight per lane
+// (3.3 TB/s next to the storage blocks, 5.3 TB/s alone) and finish 3 us after the last storage block instead of 7.
+// Static assignment: every block ends after its last item, and the partial sums stay per ITEM (fixed order, bitwise
+// reproducible whichever block computes them). (Tried: items drawn from a counter so that blocks starting late can help
+// — a same-address device-scope atomic per item costs more than it balances on eight L2s: 26 vs 21 us.)
+template <int BS>
+__device__ __forceinline__ void gen_pair_stream(const DevView &v, const int first, const int stride)
+{
+    constexpr int GU = kGenStreamRows;
+    __shared__ double red[2][2][BS];
+    __shared__ double wc[2][BS / 64];
+    const int halt = v.st->halt;                             // (in flight with the loads below)
+    const int T = v.T, N = v.N, TT = v.genTT2, R = v.genR2, nI = v.nGenItems, chunk = v.genChunk, G = v.G;
+    const int tid = threadIdx.x;
+    const int r = tid / TT, tt = tid - r * TT;
+    const bool rowlane = r < R;
+    const double gam = v.gamma, inv = 1.0 / (v.w_prox + gam);
+    const int t2c = 2 * tt;                                  // one node: its price is entry 0 of every timestep
+    const double sh0 = fma(gam, v.s[t2c], v.price[(size_t)N * t2c]) * inv;
+    const double sh1 = fma(gam, v.s[t2c + 1], v.price[(size_t)N * (t2c + 1)]) * inv;
+    if (first >= nI) return;
+    double2 *P2 = reinterpret_cast<double2 *>(v.P);
+    const size_t half = (size_t)(T >> 1);
+    double2 pa[GU], pb[GU];
+    double mca[GU], pma[GU], mcb[GU], pmb[GU];
+    // Straight-line on purpose. The wait before a use is a count of NEWER operations the in-order counter may leave
+    // outstanding, fixed per program point: any path on which the next batch's loads are skipped (no next item, a lane
+    // without a row, an early exit from the row loop) makes the compiler assume that path everywhere — the use then
+    // waits for the next batch as well and the overlap is gone. So: every lane loads every time (a valid row, dropped
+    // if it is not its own), the last item is loaded once more instead of nothing, rows are masked, not skipped.
+#define DOPF_GEN_LOAD(item, p, mc, pm)                                                      \
+    {                                                                                       \
+        const int a0_ = (item) * chunk, a1_ = min(G, a0_ + chunk);                          \
+        _Pragma("unroll") for (int u = 0; u < GU; ++u) {                                    \
+            const int g_ = (rowlane && a0_ + r + u * R < a1_) ? a0_ + r + u * R : a0_;      \
+            const double2 mp_ = v.gen_mp[g_];                                               \
+            mc[u] = mp_.x; pm[u] = mp_.y;                                                   \
+            p[u] = P2[(size_t)g_ * half + tt];                                              \
+        }                                                                                   \
     }
-    __syncthreads();
-    red[0][tid] = cost;
-    __syncthreads();
-    for (int sft = BS / 2; sft > 0; sft >>= 1) {
-        if (tid < sft) red[0][tid] += red[0][tid + sft];
-        __syncthreads();
+#define DOPF_GEN_WORK(item, p, mc, pm, par)                                                 \
+    {                                                                                       \
+        const int a0_ = (item) * chunk, a1_ = min(G, a0_ + chunk);                          \
+        double acc0 = 0.0, acc1 = 0.0, cost = 0.0;                                          \
+        _Pragma("unroll") for (int u = 0; u < GU; ++u) {                                    \
+            const int g_ = a0_ + r + u * R;                                                 \
+            const bool mine = rowlane && g_ < a1_;                                          \
+            double2 pn;            /* explicit fma: rounds exactly like gen_pair_body */     \
+            pn.x = clampd(p[u].x - fma(mc[u], inv, sh0), 0.0, pm[u]);                       \
+            pn.y = clampd(p[u].y - fma(mc[u], inv, sh1), 0.0, pm[u]);                       \
+            if (mine) {                                                                     \
+                P2[(size_t)g_ * half + tt] = pn;                                            \
+                acc0 += pn.x; acc1 += pn.y;                                                 \
+                cost = fma(mc[u], pn.x + pn.y, cost);                                       \
+            }                                                                               \
+        }                                                                                   \
+        /* two LDS buffers in turn: a lane may be one barrier ahead of the slowest reader */ \
+        gen_pair_sums<BS, true>(v, (item), tid, r, tt, acc0, acc1, cost, red[par], wc[par]); \
     }
-    if (tid == 0) v.part_gcost[blk] = red[0][0];
+    int i = first;
+    DOPF_GEN_LOAD(i, pa, mca, pma)
+    for (;;) {
+        const int j = i + stride;
+        DOPF_GEN_LOAD(min(j, nI - 1), pb, mcb, pmb)
+        if (halt) return;                                    // (uniform) nothing is stored in a halted state
+        DOPF_GEN_WORK(i, pa, mca, pma, 0)
+        if (j >= nI) break;
+        const int k = j + stride;
+        DOPF_GEN_LOAD(min(k, nI - 1), pa, mca, pma)
+        DOPF_GEN_WORK(j, pb, mcb, pmb, 1)
+        if (k >= nI) break;
+        i = k;
+    }
+#undef DOPF_GEN_LOAD
+#undef DOPF_GEN_WORK
 }
 
 __global__ __launch_bounds__(512) void k_gen_update_pair(DevView v)
@@ -229,6 +331,7 @@ template <int BS>
 __device__ __forceinline__ void gen_pair_skip_body(const DevView &v, const int blk)
 {
     __shared__ double red[2][BS];
+    __shared__ double wc[BS / 64], wlo[BS / 64], whi[BS / 64];
     __shared__ int flg[2][BS];
     const Item it = v.gen_items[blk];
     const int T = v.T, N = v.N, TT = v.genTT2, R = v.genR2;     // TT = T/2 pair columns
@@ -244,16 +347,14 @@ __device__ __forceinline__ void gen_pair_skip_body(const DevView &v, const int b
         sh1 = fma(gam, v.s[t + 1], v.price[it.node + N * (t + 1)]) * inv;
     }
     // min and max of the shift over the horizon (same for every agent of the item)
-    red[0][tid] = (r == 0 && tt < TT) ? fmin(sh0, sh1) : INFINITY;
-    red[1][tid] = (r == 0 && tt < TT) ? fmax(sh0, sh1) : -INFINITY;
+    // (min / max are exact: any order gives the same bits)
+    double lo = (r == 0 && tt < TT) ? fmin(sh0, sh1) : INFINITY, hi = (r == 0 && tt < TT) ? fmax(sh0, sh1) : -INFINITY;
+    for (int d = 32; d > 0; d >>= 1) { lo = fmin(lo, __shfl_xor(lo, d)); hi = fmax(hi, __shfl_xor(hi, d)); }
+    if ((tid & 63) == 0) { wlo[tid >> 6] = lo; whi[tid >> 6] = hi; }
     flg[0][tid] = 3; flg[1][tid] = 3;
     __syncthreads();
-    for (int sft = BS / 2; sft > 0; sft >>= 1) {
-        if (tid < sft) { red[0][tid] = fmin(red[0][tid], red[0][tid + sft]); red[1][tid] = fmax(red[1][tid], red[1][tid + sft]); }
-        __syncthreads();
-    }
-    const double smin = red[0][0], smax = red[1][0];
-    __syncthreads();
+    double smin = wlo[0], smax = whi[0];
+    for (int q = 1; q < BS / 64; ++q) { smin = fmin(smin, wlo[q]); smax = fmax(smax, whi[q]); }
 
     double2 *P2 = reinterpret_cast<double2 *>(v.P);
     const size_t half = (size_t)(T >> 1);
@@ -291,23 +392,7 @@ __device__ __forceinline__ void gen_pair_skip_body(const DevView &v, const int b
         }
         if (tt == 0 && r < R) flg[p & 1][r] = 3;              // free again two passes later
     }
-    __syncthreads();
-    red[0][tid] = acc0; red[1][tid] = acc1;
-    __syncthreads();
-    if (r == 0 && tt < TT) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int q = 0; q < R; ++q) { s0 += red[0][q * TT + tt]; s1 += red[1][q * TT + tt]; }
-        v.part_ginj[(size_t)blk * T + 2 * tt] = s0;
-        v.part_ginj[(size_t)blk * T + 2 * tt + 1] = s1;
-    }
-    __syncthreads();
-    red[0][tid] = cost;
-    __syncthreads();
-    for (int sft = BS / 2; sft > 0; sft >>= 1) {
-        if (tid < sft) red[0][tid] += red[0][tid + sft];
-        __syncthreads();
-    }
-    if (tid == 0) v.part_gcost[blk] = red[0][0];
+    gen_pair_sums<BS>(v, blk, tid, r, tt, acc0, acc1, cost, red, wc);
 }
 
 __global__ __launch_bounds__(512) void k_gen_update_pair_skip(DevView v)
@@ -1523,20 +1608,24 @@ __global__ __launch_bounds__(256, 3) void k_sto(DevView v)
 template <int LPS, int NCH, bool SKIP>
 __global__ __launch_bounds__(256, 3) void k_agents(DevView v)
 {
-    if (v.st->halt) return;
     const int nS = v.nStoItems;
-#ifdef DOPF_STATS
+#if defined(DOPF_STATS) || defined(DOPF_BLOCK_STAMPS)
     if (threadIdx.x == 0 && blockIdx.x < 8192 * 4) g_timeline[32768 + 2 * blockIdx.x] = wall_clock64();
 #endif
-    if ((int)blockIdx.x < nS) {
-        const int left = sto_warm_body<LPS, NCH, false>(v, blockIdx.x);     // ends on a __syncthreads: its sto_fail
-        sto_cold_body<LPS, NCH, false>(v, blockIdx.x, left);                // flags are visible to the block here
-    } else if (SKIP) {
-        gen_pair_skip_body<256>(v, blockIdx.x - nS);
+    if (!SKIP && (int)blockIdx.x >= nS) {
+        // generator block: its loads do not wait for the halt word
+        if (v.genBlocks > 0) gen_pair_stream<256>(v, blockIdx.x - nS, v.genBlocks);
+        else gen_pair_body<256, true>(v, blockIdx.x - nS);
     } else {
-        gen_pair_body<256>(v, blockIdx.x - nS);
+        if (v.st->halt) return;
+        if ((int)blockIdx.x < nS) {
+            const int left = sto_warm_body<LPS, NCH, false>(v, blockIdx.x);     // ends on a __syncthreads: its sto_fail
+            sto_cold_body<LPS, NCH, false>(v, blockIdx.x, left);                // flags are visible to the block here
+        } else {
+            gen_pair_skip_body<256>(v, blockIdx.x - nS);
+        }
     }
-#ifdef DOPF_STATS
+#if defined(DOPF_STATS) || defined(DOPF_BLOCK_STAMPS)
     __syncthreads();
     if (threadIdx.x == 0 && blockIdx.x < 8192 * 4) g_timeline[32768 + 2 * blockIdx.x + 1] = wall_clock64();
 #endif
@@ -1544,7 +1633,7 @@ __global__ __launch_bounds__(256, 3) void k_agents(DevView v)
 
 int debug_timeline(unsigned long long *out, int n)
 {
-#ifdef DOPF_STATS
+#if defined(DOPF_STATS) || defined(DOPF_BLOCK_STAMPS)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -1;
 #else
     (void)out; (void)n;
@@ -1580,7 +1669,7 @@ static void launch_sto_t(const DevView &v, hipStream_t s)
 template <int LPS, int NCH>
 static void launch_agents_t(const DevView &v, hipStream_t s)
 {
-    const dim3 grid(v.nStoItems + v.nGenItems);
+    const dim3 grid(v.nStoItems + (v.genBlocks > 0 && !v.genSkip ? v.genBlocks : v.nGenItems));
     if (v.genSkip) hipLaunchKernelGGL((k_agents<LPS, NCH, true>), grid, dim3(256), 0, s, v);
     else hipLaunchKernelGGL((k_agents<LPS, NCH, false>), grid, dim3(256), 0, s, v);
 }

@@ -5,7 +5,7 @@ sys.path.insert(0, os.getcwd())
 import numpy as np, dopf_pkg
 pkg = dopf_pkg.load()
 from decentralopf_jl_amd import _capi, synth
-api = _capi.CApi("scripts/tmp/libdopf_stats.so", "dopf_")
+api = _capi.CApi("scripts/tmp/libdopf_stamps.so", "dopf_")      # product code + two stamps per block (-DDOPF_BLOCK_STAMPS)
 api.lib.dopf_debug_timeline.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32]
 pp = synth.baseline_config(2); A = pp.G + pp.S
 e = _capi.Engine(api, params=_capi.default_params(gamma=1.0 / A, eps=0.0, flags=_capi.F_NO_GRAPH), **pp.engine_kwargs())
@@ -23,3 +23,10 @@ print(f"{len(sto)} storage blocks: start p50 {np.median(us(sto[:, 0])):.2f} max 
 print(f"{len(gen)} generator blocks: start p5 {np.percentile(us(gen[:, 0]), 5):.2f} p50 {np.median(us(gen[:, 0])):.2f} p95 {np.percentile(us(gen[:, 0]), 95):.2f}; end max {us(gen[:, 1]).max():.2f} us; duration p50 {np.median(gen[:, 1] - gen[:, 0]) / 100:.2f} p95 {np.percentile(gen[:, 1] - gen[:, 0], 95) / 100:.2f} us")
 h, edges = np.histogram(us(gen[:, 0]), bins=12)
 print("generator block starts per time bin:", [(round(float(a), 1), int(b)) for a, b in zip(edges[:-1], h)])
+# how many generator blocks are resident over time, and when the bytes get moved
+ts = np.arange(0, us(tl[:, 1]).max() + 0.5, 1.0)
+gs, ge = us(gen[:, 0]), us(gen[:, 1])
+ss, se = us(sto[:, 0]), us(sto[:, 1])
+print("t [us]: storage blocks resident / generator blocks resident / generator blocks finished")
+for t in ts:
+    print(f"  {t:5.1f}: {int(((ss <= t) & (se > t)).sum()):4d} {int(((gs <= t) & (ge > t)).sum()):4d} {int((ge <= t).sum()):5d}")
