@@ -324,6 +324,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         int schunk = std::max(NG, (S + 2047) / 2048);
         schunk = (schunk + NG - 1) / NG * NG;
         make_items(snode, N, schunk, sitems, nsb, nsib);
+        v.stoChunk = (N == 1 && !getenv("DOPF_NO_STO_CHUNK")) ? schunk : 0;
     }
     v.maxNodeAgents = 0;
     for (int n = 0; n < N; ++n) v.maxNodeAgents = std::max(v.maxNodeAgents, (ngb[n + 1] - ngb[n]) + (nsb[n + 1] - nsb[n]));

@@ -48,6 +48,7 @@ struct DevView {
     int nGenItems, nStoItems;
     int genTT, genR;                // generator block tiling: TT = min(T, 512) timesteps x R agents
     int genBlocks;                  // > 0 (needs genChunk): the fused launch has this many generator blocks, each walking items b, b + genBlocks, ...
+    int stoChunk;                   // > 0: one node, storage item i = storages [i*stoChunk, (i+1)*stoChunk)
     int genChunk;                   // > 0: one node, generator item i = rows [i*genChunk, (i+1)*genChunk) (no item look-up)
     int genSkip;                    // pair kernel with row skipping (blocks sweep >= 8 passes of agents)
     int genTT2, genR2;              // pair kernel (copper plate, even T <= 1024): T/2 double2 columns x R2 agents; 0 = off
@@ -101,7 +102,10 @@ struct DevView {
 
 // consensus states up to this many (n,t) / (l,t) entries take the one-block dual step
 constexpr size_t kSmallConsensus = 4096;
-constexpr int kGenStreamRows = 6;          // rows per lane and item in the streaming generator blocks (one batch of loads)
+#ifndef DOPF_STREAM_ROWS
+#define DOPF_STREAM_ROWS 6
+#endif
+constexpr int kGenStreamRows = DOPF_STREAM_ROWS;          // rows per lane and item in the streaming generator blocks (one batch of loads)
 
 struct Launch {
     int stoLPS, stoNCH;

@@ -1097,7 +1097,10 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
     __shared__ double redc[256];
     const int tid = threadIdx.x, lane = tid & 63, li = tid & (LPS - 1), grp = tid / LPS;
     const int gbase = lane & ~(LPS - 1);
-    const Item it = v.sto_items[blk];
+    // one node: the items are equal cuts of the storage list — no table look-up between the block's start and its loads
+    Item it;
+    if (v.stoChunk > 0) { it.a0 = blk * v.stoChunk; it.a1 = min(v.S, it.a0 + v.stoChunk); it.node = 0; }
+    else it = v.sto_items[blk];
     const int T = v.T, N = v.N;
     const double w = v.w_prox, gam = v.gamma;
     const double a0 = w + gam, ia0 = 1.0 / a0, idet0 = 1.0 / (a0 * a0 - gam * gam), s20 = 2.0 / (a0 + gam);
@@ -1157,7 +1160,8 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
             const bool ok = live && t < T;
             const size_t e = (size_t)s * T + (ok ? t : 0);
             const double d0 = ok ? v.D[e] : 0.0, c0 = ok ? v.C[e] : 0.0;
-            nuv[c] = (ok && havenu) ? v.nu_prev[e] : 0.0;      // no stored prices (zero state, set_state): start from 0
+            const double nu_st = v.nu_prev[e];                 // (always loaded: a load behind the nu_valid word would be a second round trip)
+            nuv[c] = (ok && havenu) ? nu_st : 0.0;             // no stored prices (zero state, set_state): start from 0
             hint[c] = 0;
             run += c0 - d0;
             if (LINES) { A0[c] = d0; B0[c] = c0; }
