@@ -308,7 +308,8 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         const int R = v.genTT2 ? v.genR2 : v.genR;
         // ~2048 blocks fill the chip several times over; in the fused launch the generator blocks share the wave slots with
         // the storage blocks and ~1536 somewhat larger ones come out ahead (measured on config2: 25.7 -> 24.0 us)
-        int target_items = v.fuseAgents ? 1536 : 2048;
+        // (with lines ~1024 blocks: the 118-node share 93.8 -> 87.3 us per iteration, config3 at full size 204 -> 203)
+        int target_items = v.fuseAgents ? 1536 : (L > 0 ? 1024 : 2048);
         if (const char *e = getenv("DOPF_GEN_TARGET_ITEMS")) target_items = std::max(1, atoi(e));     // (experiments)
         // streaming generator blocks (fused launch, one node): an item is ONE batch of loads, <= kGenStreamRows rows per lane
         const bool stream = v.fuseAgents && N == 1 && !getenv("DOPF_NO_GEN_STREAM");
@@ -407,6 +408,8 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     TRY(dev_alloc(c, &v.item_fail, v.nStoItems));
     TRY(dev_alloc(c, &v.part2, (size_t)N * v.reduceRB * T)); TRY(dev_alloc(c, &v.part2_cost, v.reduceRB));
     TRY(dev_alloc(c, &v.reduce_ticket, (size_t)N * ((T + 31) / 32)));
+    TRY(dev_alloc(c, &v.dual_ticket, 1));
+    v.splitDual = getenv("DOPF_SPLIT_DUAL") ? 1 : 0;
     double *cons = nullptr;
     TRY(dev_alloc(c, &cons, NT + 2 * LT + 1));
     c->own_cons = cons;

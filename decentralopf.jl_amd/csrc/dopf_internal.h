@@ -48,6 +48,7 @@ struct DevView {
     int nGenItems, nStoItems;
     int genTT, genR;                // generator block tiling: TT = min(T, 512) timesteps x R agents
     int genBlocks;                  // > 0 (needs genChunk): the fused launch has this many generator blocks, each walking items b, b + genBlocks, ...
+    int splitDual;                  // (experiments, DOPF_SPLIT_DUAL=1) networks: dual and price steps as two launches
     int stoChunk;                   // > 0: one node, storage item i = storages [i*stoChunk, (i+1)*stoChunk)
     int genChunk;                   // > 0: one node, generator item i = rows [i*genChunk, (i+1)*genChunk) (no item look-up)
     int genSkip;                    // pair kernel with row skipping (blocks sweep >= 8 passes of agents)
@@ -95,6 +96,7 @@ struct DevView {
     int *tab_skip;                                  // [t] the price kernel has written the (empty) tables of timestep t
     int *walk_flag, *walk_any;                      // [l + L*t], [t]: the slack sums of (l,t) need the per-node cases (set by the dual step)
     double *part2, *part2_cost;                     // [(n*RB + rb)*T + t], [rb]
+    int *dual_ticket;                               // [1] blocks of the one-launch dual/price kernel that have finished
     int *reduce_ticket;                             // [n]
     double *cons;
     Status *st;

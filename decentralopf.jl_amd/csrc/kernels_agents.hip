@@ -139,13 +139,16 @@ __global__ __launch_bounds__(512) void k_gen_update(DevView v)
         }
         __syncthreads();
     }
-    red[tid] = cost;
+    // cost: butterfly inside each wave, then the eight waves in order — one barrier instead of one per tree level
+    __shared__ double wcost[8];
+    for (int d = 32; d > 0; d >>= 1) cost += __shfl_xor(cost, d);
+    if ((tid & 63) == 0) wcost[tid >> 6] = cost;
     __syncthreads();
-    for (int sft = 256; sft > 0; sft >>= 1) {
-        if (tid < sft) red[tid] += red[tid + sft];
-        __syncthreads();
+    if (tid == 0) {
+        double c = 0.0;
+        for (int q = 0; q < 8; ++q) c += wcost[q];
+        v.part_gcost[blockIdx.x] = c;
     }
-    if (tid == 0) v.part_gcost[blockIdx.x] = red[0];
 }
 
 // End of a generator block of the pair kernels: per-column sums of the R agent lanes and the block's cost, every sum in
@@ -385,7 +388,9 @@ __device__ __forceinline__ void gen_pair_skip_body(const DevView &v, const int b
                 if (bits != 3) atomicAnd(&flg[p & 1][r], bits);
             }
         }
-        __syncthreads();
+        // only LDS data (the flags) crosses this barrier: __syncthreads() would also wait for this pass's row stores to be
+        // acknowledged (s_waitcnt vmcnt(0)) before the next pass may issue its loads
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (full && tt == 0) {
             const int bits = flg[p & 1][r];
             v.gen_state[g] = (bits & 1) ? 0 : ((bits & 2) ? 1 : 2);

@@ -977,6 +977,163 @@ __global__ __launch_bounds__(256) void k_price_t(DevView v)
     }
 }
 
+// Networks with L <= 256 lines and N <= 256 nodes (BASELINE configs[3]: 118 / 186): dual step, prices, linear Psi
+// pieces and the stop test of timestep t in ONE block of 1024 threads — what k_dual_t + k_price_t do in two launches
+// with the new duals travelling through global memory in between. Both halves are chains of L2-latency-bound dot
+// products over the PTDF matrix; here a thread's share of a dot product is two batches of 16 rows, the old
+// line state is on its way while the flows are formed, mu - rho and the G / S terms of the linear pieces go from the
+// dual half to the price half through LDS, and the residual maxima meet in a ticket: the block that finishes last runs
+// the stop test (one atomic round trip per block instead of a launch). Every sum has a fixed order.
+template <bool UPDATE>
+__global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
+{
+    if (UPDATE && v.st->halt) return;
+    extern __shared__ double sh[];               // q[N] injections | d[L] mu - rho | G[L] | S[L]
+    __shared__ double red[3][1024];
+    __shared__ double wsum[4], wmx[2][4];
+    __shared__ int wany[4], wnz[4], lastBlock;
+    const int tid = threadIdx.x, lane = tid & 63, t = blockIdx.x;
+    const int N = v.N, L = v.L, T = v.T;
+    const size_t NT = (size_t)N * T, LT = (size_t)L * T;
+    double *q = sh, *dd = sh + N, *Gl = dd + L, *Sl = Gl + L;
+    const double *cinj = v.cons, *cU = v.cons + NT, *cK = cU + LT;
+    const double g = v.gamma, w2 = 2.0 * v.w_flow, inv = 1.0 / (w2 + g);
+
+    // ---- dual half: thread (node part pl, line l) --------------------------------------------------------------
+    const int pl = tid >> 8, l = tid & 255;
+    const bool lt = pl == 0 && l < L;
+    const size_t i = (size_t)(l < L ? l : 0) + (size_t)L * t;
+    double f_old = 0.0, aU_old = 0.0, aK_old = 0.0, mo = 0.0, ro = 0.0, F = 0.0, sU = 0.0, sK = 0.0, reach = 0.0;
+    if (lt) {                                    // (in flight while the flows are formed)
+        f_old = v.flow[i]; aU_old = v.avgU[i]; aK_old = v.avgK[i]; mo = v.mu[i]; ro = v.rho[i];
+        F = v.fmax[l]; sU = cU[i]; sK = cK[i]; reach = v.line_reach[l];
+    }
+    const double lam_old = v.lam[t], s_old = v.s[t];
+    const int Nc = (((N + 3) / 4) + 7) & ~7, nbeg = pl * Nc, nend = min(N, nbeg + Nc);
+    double x = 0.0;
+    if (tid < N) {
+        x = cinj[tid + (size_t)N * t] - v.demand[tid + (size_t)N * t];       // results.jl:58-100
+        q[tid] = x;
+        v.inj[tid + (size_t)N * t] = x;
+    }
+    {   // imbalance: butterfly inside each of the (at most four) waves that hold nodes, waves in order
+        double ps = x;
+        for (int d = 32; d > 0; d >>= 1) ps += __shfl_xor(ps, d);
+        if (lane == 0 && tid < 256) wsum[tid >> 6] = ps;
+    }
+    __syncthreads();
+    const double sum = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+    const double ln = UPDATE ? lam_old + g * sum : lam_old;                     // update_duals.jl:8-13
+    if (tid == 0) {
+        if (UPDATE) { v.s_used[t] = s_old; v.lam_used[t] = lam_old; v.lam[t] = ln; }
+        v.s[t] = sum;
+    }
+    double f = 0.0;
+    if (l < L)
+        for (int n0 = nbeg; n0 < nend; n0 += 16) {                             // sixteen rows of ptdf in flight (more would spill at 1024 threads)
+            double h[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) h[u] = n0 + u < nend ? v.ptdf[l + (size_t)L * (n0 + u)] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) f += h[u] * (n0 + u < nend ? q[n0 + u] : 0.0);
+        }
+    red[0][tid] = f;
+    __syncthreads();
+    double rm = 0.0, rr = 0.0;
+    int flag = 0, nzl = 0;
+    if (lt) {
+        f = ((red[0][l] + red[0][256 + l]) + red[0][512 + l]) + red[0][768 + l];
+        double aU = aU_old, aK = aK_old, mn = mo, rn = ro;
+        if (UPDATE) {
+            v.flow_used[i] = f_old; v.avgU_used[i] = aU_old; v.avgK_used[i] = aK_old;
+            aU = v.invA * sU; aK = v.invA * sK;                                  // results.jl:108-112
+            v.avgU[i] = aU; v.avgK[i] = aK;
+            mn = (mo + g * (f + aU - F)) * (aU <= v.mask_thr ? 1.0 : 0.0);       // update_duals.jl:18-25
+            rn = (ro + g * (aK - f - F)) * (aK <= v.mask_thr ? 1.0 : 0.0);       // :30-37
+            v.mu_used[i] = mo; v.rho_used[i] = ro;
+            v.mu[i] = mn; v.rho[i] = rn;
+            rm = fabs(mn - mo); rr = fabs(rn - ro);
+        }
+        v.flow[i] = f;                                                            // results.jl:114
+        // what the next slack sums of (l,t) will need (k_slack / k_reduce)
+        flag = slack_needs_cases(g, w2, inv, f, F, aU, aK, reach) ? 1 : 0;
+        v.walk_flag[i] = flag;
+        // price half: mu - rho, and the terms of the linear Psi pieces (used when no line of t is flagged)
+        const double dx = mn - rn;
+        dd[l] = dx;
+        nzl = dx != 0.0;
+        const double U0 = dmax0((g * aU - w2 * (f - F)) * inv), K0 = dmax0((g * aK + w2 * (f + F)) * inv);
+        Gl[l] = w2 * ((f + U0 - F) - (K0 - f - F));
+        Sl[l] = w2 * (2.0 - ((U0 > 0.0 ? 1.0 : 0.0) + (K0 > 0.0 ? 1.0 : 0.0)) * w2 * inv);
+    }
+    if (tid < 256) {                             // the four waves that hold lines: OR / max inside the wave (order independent)
+        const int a = __any(flag), z = __any(nzl);
+        for (int d = 32; d > 0; d >>= 1) { rm = fmax(rm, __shfl_xor(rm, d)); rr = fmax(rr, __shfl_xor(rr, d)); }
+        if (lane == 0) { wany[tid >> 6] = a; wnz[tid >> 6] = z; wmx[0][tid >> 6] = rm; wmx[1][tid >> 6] = rr; }
+    }
+    __syncthreads();
+    const int anyNeed = wany[0] | wany[1] | wany[2] | wany[3];
+    const int nz = wnz[0] | wnz[1] | wnz[2] | wnz[3];
+    const bool lin = !anyNeed;
+
+    // ---- price half: thread (line part pp, node n) -------------------------------------------------------------
+    const int NP = N <= 128 ? 128 : 256, P = 1024 / NP;
+    const int pp = tid / NP, n = tid - pp * NP;
+    const int Lc = (((L + P - 1) / P) + 7) & ~7, lbeg = pp * Lc, lend = min(L, lbeg + Lc);
+    double pr = 0.0, psx = 0.0, sl = 0.0;
+    if (n < N && (nz || lin))
+        for (int l0 = lbeg; l0 < lend; l0 += 16) {                             // ptdfT[n + N l]: coalesced over the nodes
+            double h[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) h[u] = l0 + u < lend ? v.ptdfT[n + (size_t)N * (l0 + u)] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (l0 + u < lend) {
+                    pr += h[u] * dd[l0 + u];
+                    if (lin) { psx += h[u] * Gl[l0 + u]; sl += h[u] * h[u] * Sl[l0 + u]; }
+                }
+            }
+        }
+    red[0][tid] = pr; red[1][tid] = psx; red[2][tid] = sl;
+    __syncthreads();
+    if (pp == 0 && n < N) {
+        for (int k = 1; k < P; ++k) { pr += red[0][k * NP + n]; psx += red[1][k * NP + n]; sl += red[2][k * NP + n]; }
+        const size_t at = n + (size_t)N * t;
+        pr += ln;
+        v.price[at] = pr;
+        if (lin) {
+            v.tb_m[at] = 0;
+            v.tb_psi0[at] = (pr + g * sum) + psx;
+            v.tb_slope[at * (v.M2 + 1)] = g + sl;
+        }
+    }
+    if (tid == 0) { v.walk_any[t] = anyNeed ? 1 : 0; v.tab_skip[t] = lin ? 1 : 0; }
+    if (UPDATE) {
+        // residual maxima of this timestep, then the ticket: whoever is last has every block's maxima behind it
+        if (tid == 0) {
+            const double rl = fabs(ln - lam_old);
+            const double bm = fmax(fmax(wmx[0][0], wmx[0][1]), fmax(wmx[0][2], wmx[0][3]));
+            const double br = fmax(fmax(wmx[1][0], wmx[1][1]), fmax(wmx[1][2], wmx[1][3]));
+            if (rl > 0.0) atomic_max_pos(&v.st->resbits[0], rl);
+            if (bm > 0.0) atomic_max_pos(&v.st->resbits[1], bm);
+            if (br > 0.0) atomic_max_pos(&v.st->resbits[2], br);
+            if (t == 0) v.st->total_cost = v.cons[NT + 2 * LT];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const int last = atomicAdd(v.dual_ticket, 1) == T - 1;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                Status *st = v.st;
+                const double r0 = __longlong_as_double((long long)__hip_atomic_load(&st->resbits[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const double r1 = __longlong_as_double((long long)__hip_atomic_load(&st->resbits[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const double r2 = __longlong_as_double((long long)__hip_atomic_load(&st->resbits[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                st->resbits[0] = st->resbits[1] = st->resbits[2] = 0ull;
+                *v.dual_ticket = 0;
+                status_update(v, r0, r1, r2);
+            }
+        }
+    }
+}
+
 // dual step + prices + stop test in ONE block when the consensus state is small (every copper-plate case):
 // saves a launch per iteration, which is what the small configurations are bound by
 // XCHG (copper plate, peer exchange): the sum over the ranks happens HERE, between the slice sums and the dual step —
@@ -1186,6 +1343,10 @@ void launch_dual(const DevView &v, hipStream_t s, const XchgView *xd)
         else hipLaunchKernelGGL((k_dual_price_small<true, false>), dim3(1), dim3(256), 0, s, v, XchgView{});
         return;
     }
+    if (v.L > 0 && v.L <= 256 && v.N <= 256 && !v.splitDual) {
+        hipLaunchKernelGGL(k_dual_price_t1024<true>, dim3(v.T), dim3(1024), ((size_t)v.N + 3 * (size_t)v.L) * sizeof(double), s, v);
+        return;
+    }
     if ((size_t)std::max(v.N, 3 * v.L) * sizeof(double) <= 48 * 1024) {
         hipLaunchKernelGGL(k_dual_t<true>, dim3(v.T * (v.L > 0 ? (v.L + 63) / 64 : 1)), dim3(256), (size_t)v.N * sizeof(double), s, v);
         hipLaunchKernelGGL(k_price_t<true>, dim3(v.T), dim3(256), 3 * (size_t)v.L * sizeof(double), s, v);
@@ -1235,6 +1396,10 @@ void launch_derive(const DevView &v, hipStream_t s, bool from_primal)
     }
     if (n1 <= kSmallConsensus) {
         hipLaunchKernelGGL((k_dual_price_small<false, false>), dim3(1), dim3(256), 0, s, v, XchgView{});
+        return;
+    }
+    if (v.L > 0 && v.L <= 256 && v.N <= 256 && !v.splitDual) {
+        hipLaunchKernelGGL(k_dual_price_t1024<false>, dim3(v.T), dim3(1024), ((size_t)v.N + 3 * (size_t)v.L) * sizeof(double), s, v);
         return;
     }
     if ((size_t)std::max(v.N, 3 * v.L) * sizeof(double) <= 48 * 1024) {
