@@ -450,104 +450,105 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
             if (tid == 0) v.reduce_ticket[n * TC + tcx] = 0;       // ready for the next iteration
         }
     } else {
-        // slack sums: one block per timestep (U, then K); the change of every node's injection in this iteration — new minus
-        // previous sum of its items' partials — and the nodes' constants are staged in LDS, a thread owns a line and walks
-        // the nodes in a fixed order (eight ptdf loads in flight)
+        // slack sums: block (timestep, U | K, group of 64 lines); thread (node part, line) covers a quarter of the nodes —
+        // 4x the loads in flight of one thread per line walking all N nodes (these are chains of L2-latency-bound ptdf
+        // reads) — and the four partial sums meet in LDS, added in part order. The change of every node's injection in
+        // this iteration (new minus previous sum of its items' partials) and the nodes' constants are staged in LDS.
         extern __shared__ double nsh[];               // [N] node changes of timestep t | [N] window | [N] agents at the node
+        __shared__ double pred[256];
         double *sdL = nsh, *winL = nsh + N, *naL = nsh + 2 * N;
-        const int b2 = blockIdx.x - N * RB * TC, t = b2 >> 1, which = b2 & 1;
+        const int LB = (L + 63) / 64;
+        const int b2 = blockIdx.x - N * RB * TC, lb = b2 % LB, tw = b2 / LB, t = tw >> 1, which = tw & 1;
         for (int n = tid; n < N; n += 256) {
             sdL[n] = v.node_dsum[n + (size_t)N * t];
             winL[n] = v.node_win[n];
             naL[n] = (double)((v.node_gen_beg[n + 1] - v.node_gen_beg[n]) + (v.node_sto_beg[n + 1] - v.node_sto_beg[n]));
         }
         __syncthreads();
-        {
+        const int pr = tid >> 6, ll = tid & 63, l = lb * 64 + ll;
+        const int Nc = (((N + 3) / 4) + 7) & ~7, nbeg = pr * Nc, nend = min(N, nbeg + Nc);
         const double *src = which ? v.part_K : v.part_U;
         const double w2 = 2.0 * v.w_flow, g = v.gamma, inv = 1.0 / (w2 + g);
-        for (int l = tid; l < L; l += 256) {
+        double partial = 0.0;
+        if (l < L && nbeg < nend) {
             const size_t rem = l + (size_t)L * t;
             const double f = v.flow[rem], F = v.fmax[l], cu = v.avgU[rem], ck = v.avgK[rem];
             if (!v.walk_flag[rem]) {
                 // every agent of every node has this slack active, or none has: sum_a (aX -+ kap_n d_a) = A aX -+ (w2 inv) sum_n h_n D_n
                 const SlackCase c0 = slack_case(g, w2, inv, 0.0, f, F, cu, ck, 0.0);
                 const double a = which ? c0.aK : c0.aU;
-                double out = 0.0;
                 if (a > 0.0) {
                     double dot = 0.0, cnt = 0.0;
-                    for (int n0 = 0; n0 < N; n0 += 8) {
-                        double h[8];
+                    for (int n0 = nbeg; n0 < nend; n0 += 16) {
+                        double h[16];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) h[u] = n0 + u < N ? v.ptdf[l + (size_t)L * (n0 + u)] : 0.0;
+                        for (int u = 0; u < 16; ++u) h[u] = n0 + u < nend ? v.ptdf[l + (size_t)L * (n0 + u)] : 0.0;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (n0 + u < N) { dot += h[u] * sdL[n0 + u]; cnt += naL[n0 + u]; }
+                        for (int u = 0; u < 16; ++u)
+                            if (n0 + u < nend) { dot += h[u] * sdL[n0 + u]; cnt += naL[n0 + u]; }
                     }
-                    out = which ? cnt * a + (w2 * inv) * dot : cnt * a - (w2 * inv) * dot;
+                    partial = which ? cnt * a + (w2 * inv) * dot : cnt * a - (w2 * inv) * dot;
                 }
-                v.cons[(size_t)N * T + (size_t)which * L * T + rem] = out;
-                continue;
-            }
-            // pass 1, all nodes in order: closed forms are added at once, the nodes k_slack had to walk are remembered in a
-            // bit mask (a load whose address hangs on this arithmetic would put two dependent memory round trips into
-            // every batch); pass 2 fetches the walked sums, eight in flight. Both orders are fixed: deterministic.
-            constexpr int MW = 8;                              // mask words: up to 256 nodes (more: walked inline below)
-            unsigned wm[MW];
+            } else {
+                // pass 1, the part's nodes in order: closed forms are added at once, the nodes k_slack had to walk are
+                // remembered in a bit mask (a load whose address hangs on this arithmetic would put two dependent memory
+                // round trips into every batch); pass 2 fetches the walked sums, eight in flight. Both orders are fixed.
+                constexpr int MW = 4;                              // mask words: a part of up to 128 nodes (more: fetched inline)
+                unsigned wm[MW];
 #pragma unroll
-            for (int q = 0; q < MW; ++q) wm[q] = 0u;
-            double sum = 0.0;
-            double hn[8];
+                for (int q = 0; q < MW; ++q) wm[q] = 0u;
+                double sum = 0.0;
+                for (int n0 = nbeg; n0 < nend; n0 += 8) {
+                    double h[8], x[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) hn[u] = v.ptdf[l + (size_t)L * (u < N ? u : N - 1)];
-            for (int n0 = 0; n0 < N; n0 += 8) {
-                double h[8], x[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) h[u] = hn[u];
-                if (n0 + 8 < N) {                              // next batch's rows are on their way while this one is worked
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) hn[u] = v.ptdf[l + (size_t)L * (n0 + 8 + u < N ? n0 + 8 + u : N - 1)];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int n = n0 + u < N ? n0 + u : N - 1;
-                    const SlackCase c = slack_case(g, w2, inv, h[u], f, F, cu, ck, winL[n]);
-                    const double a = which ? c.aK : c.aU;
-                    const bool live = n0 + u < N, all_on = a - c.reach >= 0.0, walked = live && !all_on && a + c.reach > 0.0;
-                    x[u] = (live && all_on) ? (which ? naL[n] * c.aK + c.kap * sdL[n] : naL[n] * c.aU - c.kap * sdL[n]) : 0.0;
-                    if (walked) {
-                        if (n < 32 * MW) {
-#pragma unroll
-                            for (int q = 0; q < MW; ++q)
-                                if (q == (n >> 5)) wm[q] |= 1u << (n & 31);
-                        } else {
-                            x[u] = src[((size_t)n + (size_t)N * t) * L + l];
-                        }
-                    }
-                }
-                sum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-            }
-#pragma unroll
-            for (int q = 0; q < MW; ++q) {
-                unsigned m = wm[q];
-                while (m) {
-                    double x[8];
+                    for (int u = 0; u < 8; ++u) h[u] = v.ptdf[l + (size_t)L * (n0 + u < nend ? n0 + u : nend - 1)];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        x[u] = 0.0;
-                        if (m) {
-                            const int n = 32 * q + __builtin_ctz(m);
-                            m &= m - 1u;
-                            x[u] = src[((size_t)n + (size_t)N * t) * L + l];
+                        const int n = n0 + u < nend ? n0 + u : nend - 1;
+                        const SlackCase c = slack_case(g, w2, inv, h[u], f, F, cu, ck, winL[n]);
+                        const double a = which ? c.aK : c.aU;
+                        const bool live = n0 + u < nend, all_on = a - c.reach >= 0.0, walked = live && !all_on && a + c.reach > 0.0;
+                        x[u] = (live && all_on) ? (which ? naL[n] * c.aK + c.kap * sdL[n] : naL[n] * c.aU - c.kap * sdL[n]) : 0.0;
+                        if (walked) {
+                            const int k = n - nbeg;
+                            if (k < 32 * MW) {
+#pragma unroll
+                                for (int q = 0; q < MW; ++q)
+                                    if (q == (k >> 5)) wm[q] |= 1u << (k & 31);
+                            } else {
+                                x[u] = src[((size_t)n + (size_t)N * t) * L + l];
+                            }
                         }
                     }
                     sum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
                 }
+#pragma unroll
+                for (int q = 0; q < MW; ++q) {
+                    unsigned m = wm[q];
+                    while (m) {
+                        double x[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            x[u] = 0.0;
+                            if (m) {
+                                const int n = nbeg + 32 * q + __builtin_ctz(m);
+                                m &= m - 1u;
+                                x[u] = src[((size_t)n + (size_t)N * t) * L + l];
+                            }
+                        }
+                        sum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+                    }
+                }
+                partial = sum;
             }
-            v.cons[(size_t)N * T + (size_t)which * L * T + rem] = sum;
         }
-        }
+        pred[tid] = partial;
+        __syncthreads();
+        if (pr == 0 && l < L)
+            v.cons[(size_t)N * T + (size_t)which * L * T + l + (size_t)L * t] = ((pred[ll] + pred[64 + ll]) + pred[128 + ll]) + pred[192 + ll];
     }
 }
+
 
 // set_state support: the items' injection sums of the state handed in (what the next iteration's node changes refer to)
 __global__ __launch_bounds__(256) void k_derive_items(DevView v)
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(256) void k_derive_items(DevView v)
 void launch_reduce(const DevView &v, hipStream_t s)
 {
     const int TC = (v.T + 31) / 32;
-    const int blocks = v.N * v.reduceRB * TC + (v.L > 0 ? 2 * v.T : 0);
+    const int blocks = v.N * v.reduceRB * TC + (v.L > 0 ? 2 * v.T * ((v.L + 63) / 64) : 0);
     hipLaunchKernelGGL(k_reduce, dim3(blocks), dim3(256), v.L > 0 ? 3 * (size_t)v.N * sizeof(double) : 0, s, v);
 }
 
