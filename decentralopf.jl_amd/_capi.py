@@ -64,6 +64,7 @@ F_DEBUG_ROOT_CAP = 128
 F_KEEP_DELTAS = 256
 F_COMM_GRAPH = 512
 F_COMM_P2P = 1024
+F_DEBUG_LEAVE = 2048
 COMM_ID_BYTES = 128
 XCHG_HANDLE_BYTES = 64
 

@@ -266,6 +266,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     v.max_iters = q->max_iters;
     v.rootCap = (q->flags & DOPF_F_DEBUG_ROOT_CAP) ? 2 : 80;
     v.keepDeltas = (q->flags & DOPF_F_KEEP_DELTAS) ? 1 : 0;
+    v.debugLeave = (q->flags & DOPF_F_DEBUG_LEAVE) ? 1 : 0;
     const int A = q->n_agents_global > 0 ? q->n_agents_global : G + S;
     v.invA = A > 0 ? 1.0 / (double)A : 0.0;
     v.use_warm = (S > 0 && lc.stoNCH <= 3 && !(q->flags & DOPF_F_NO_WARM_START)) ? 1 : 0;
@@ -423,6 +424,13 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     HIPTRY(hipGetLastError());
     HIPTRY(hipStreamSynchronize(c->main));
     c->host_st = st0;
+    v.coldInWarm = (L > 0 && v.use_warm && !getenv("DOPF_SPLIT_COLD")) ? 1 : 0;
+    {   // the view itself in device memory (non-inlined device functions take a pointer to it)
+        DevView *dv = nullptr;
+        TRY(dev_alloc(c, &dv, 1, false));
+        v.self = dv;
+        HIPTRY(hipMemcpy(dv, &v, sizeof(DevView), hipMemcpyHostToDevice));
+    }
 #undef TRY
 #undef HIPTRY
     *out = c;
@@ -585,6 +593,7 @@ int dopf_bind_consensus(dopf_ctx *c, void *device_ptr)
     DeviceGuard guard(c->device);
     HIPCHK(c, hipStreamSynchronize(c->main));
     c->v.cons = device_ptr ? (double *)device_ptr : (double *)c->own_cons;
+    HIPCHK(c, hipMemcpy(const_cast<DevView *>(c->v.self), &c->v, sizeof(DevView), hipMemcpyHostToDevice));
     drop_graphs(c);
     return DOPF_OK;
 }

@@ -43,11 +43,14 @@ struct Status {
 };
 
 struct DevView {
+    const DevView *self;            // this view in device memory (what a non-inlined device function is handed)
     int N, L, T, G, S, M2;          // M2 = 2L
     int maxNodeAgents;              // most agents (generators + storages) at one node
     int nGenItems, nStoItems;
     int genTT, genR;                // generator block tiling: TT = min(T, 512) timesteps x R agents
     int genBlocks;                  // > 0 (needs genChunk): the fused launch has this many generator blocks, each walking items b, b + genBlocks, ...
+    int debugLeave;                 // DOPF_F_DEBUG_LEAVE (tests)
+    int coldInWarm;                 // networks: k_sto_warm calls the scan body itself for what it leaves over (no k_sto_update launch)
     int splitDual;                  // (experiments, DOPF_SPLIT_DUAL=1) networks: dual and price steps as two launches
     int stoChunk;                   // > 0: one node, storage item i = storages [i*stoChunk, (i+1)*stoChunk)
     int genChunk;                   // > 0: one node, generator item i = rows [i*genChunk, (i+1)*genChunk) (no item look-up)

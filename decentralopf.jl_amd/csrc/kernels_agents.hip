@@ -1504,7 +1504,8 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
                     }
                 }
             }
-            const bool cert = nconv && group_bits<LPS>(!okk, gbase) == 0ull;
+            // (debugLeave, tests: every third storage is declared uncertified, so that the hand-over to the scan body runs)
+            const bool cert = nconv && group_bits<LPS>(!okk, gbase) == 0ull && !(v.debugLeave && s % 3 == 0);
             bool chg = false;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) chg = chg || nkind[c] != kind[c];
@@ -1590,11 +1591,28 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
     return blockFail;
 }
 
+// The scan body as a function of its own (networks): called by k_sto_warm for the rare item the active-set body leaves
+// something of. Inlined, its registers crowd the active-set body (255 VGPRs and spills, 40 % slower, measured); as a
+// separate launch it cost 4 us + a launch gap per iteration for finding nothing to do.
+template <int LPS, int NCH>
+__device__ __attribute__((noinline)) void sto_cold_lines_call(const DevView *self, const int blk, const int left)
+{
+    sto_cold_body<LPS, NCH, true>(*self, blk, left);
+}
+
 template <int LPS, int NCH, bool LINES>
 __global__ __launch_bounds__(256, 2) void k_sto_warm(DevView v)
 {
     if (v.st->halt) return;
-    sto_warm_body<LPS, NCH, LINES>(v, blockIdx.x);
+    const int left = sto_warm_body<LPS, NCH, LINES>(v, blockIdx.x);         // ends on a __syncthreads
+    if (LINES && v.coldInWarm) {
+        if (left == 0) {                         // (what the scan body writes when there is nothing for it)
+            for (int t = threadIdx.x; t < v.T; t += 256) v.part_sinj[(size_t)blockIdx.x * v.T + t] = 0.0;
+            if (threadIdx.x == 0) v.part_scost[blockIdx.x] = 0.0;
+        } else {
+            sto_cold_lines_call<LPS, NCH>(v.self, blockIdx.x, left);
+        }
+    }
 }
 
 // Warm start and, in the same block, the cold scan for what it left over: one launch for the storages of the big
@@ -1671,6 +1689,7 @@ static void launch_sto_t(const DevView &v, hipStream_t s)
     }
     // with lines the two kernels stay apart: fused, the warm part runs 40 % slower (255 VGPRs, measured)
     if (v.use_warm) hipLaunchKernelGGL((k_sto_warm<LPS, (NCH <= 3 ? NCH : 3), true>), dim3(v.nStoItems), dim3(256), 0, s, v);
+    if (v.use_warm && v.L > 0 && v.coldInWarm) return;            // the warm kernel has called the scan body where needed
     if (v.L > 0) hipLaunchKernelGGL((k_sto_update<LPS, NCH, true>), dim3(v.nStoItems), dim3(256), 0, s, v);
     else hipLaunchKernelGGL((k_sto_update<LPS, NCH, false>), dim3(v.nStoItems), dim3(256), 0, s, v);
 }

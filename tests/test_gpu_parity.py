@@ -512,3 +512,31 @@ def test_hip_storage_kernels_on_random_states(hip_api, oracle_api, T, n_cases):
                 worst, where = max_diff(st[0], st[2], keys=["D", "C", "E", "P", "lam", "inj"])
                 assert worst < 2e-5, (T, i, step, where, worst)
         assert h.solver_failures() == 0
+
+
+@pytest.mark.parametrize("shape", ["fused launch", "storage kernel of big grids", "network"])
+def test_hand_over_from_the_active_set_body_to_the_scan_body(hip_api, shape):
+    """DOPF_F_DEBUG_LEAVE makes the active-set storage body leave every third storage to the scan body, in the same launch
+    (copper plates) or through the non-inlined call (networks). Both are exact solvers of the same QP: the run must equal the
+    ordinary one, and the statistics must show that the scan body really served its share."""
+    if shape == "fused launch":
+        pp = synth.synthetic_case(700, 90, 96, seed=5)
+        g, kw = 1.0 / 790, {}
+    elif shape == "storage kernel of big grids":
+        pp = synth.synthetic_case(900, 120, 24, seed=9)
+        g, kw = 1.0 / 1020, dict(flags=_capi.F_NO_FUSE)
+    else:
+        pp = synth.synthetic_case(400, 60, 24, N=5, L=6, seed=12, fmax_factor=0.8, fmax_min=5)
+        g, kw = 0.01, dict(w_flow=0.3 / 460)
+    ref = make_engine(hip_api, pp, eps=0.0, gamma=g, **kw)
+    fl = kw.pop("flags", 0) | _capi.F_DEBUG_LEAVE
+    e = make_engine(hip_api, pp, eps=0.0, gamma=g, flags=fl, **kw)
+    for k in (1, 3, 12):
+        ref.iterate(k)
+        e.iterate(k)
+        assert e.warm_start_stats()[1] >= pp.S // 3 and ref.warm_start_stats()[1] < pp.S // 3
+        a, b = state_of(e), state_of(ref)
+        for key in a:
+            if a[key].size:
+                assert np.abs(a[key] - b[key]).max() <= 1e-8 * max(1.0, np.abs(b[key]).max()), (shape, key, k)
+    assert e.solver_failures() == 0
