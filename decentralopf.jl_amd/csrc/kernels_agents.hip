@@ -614,6 +614,24 @@ __device__ __forceinline__ void eval_lines(const TabRef &tb, int &hint, double w
     psi_cur = theta + kap * (dd - cc);       // Psi at the step's current net injection
 }
 
+// The same two as functions of their own, for the active-set body: there a (node, timestep) with a non-empty table is
+// the rare case (none in the settled state), and inlined their registers cost the common path a wave per SIMD.
+struct EvalOut { double dd, cc, s1, pc; int hint; };
+__device__ __attribute__((noinline)) EvalOut eval_lines_call(const DevView *self, int node, int t, int hint, double mc, double pm,
+                                                             double D0, double C0, double nu)
+{
+    const DevView &v = *self;
+    const TabRef tb = tab_ref(v, node, t);
+    EvalOut o;
+    o.hint = hint;
+    eval_lines(tb, o.hint, v.w_prox, 1.0 / v.w_prox, mc, pm, D0, C0, nu, o.dd, o.cc, o.s1, o.pc);
+    return o;
+}
+__device__ __attribute__((noinline)) double tab_psi_call(const DevView *self, int node, int t, double dl)
+{
+    return tab_psi_at(tab_ref(*self, node, t), dl);
+}
+
 struct StoAgent {
     double mc, pm, em;
 };
@@ -1186,9 +1204,8 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
                 box2(w + lkap[c], lkap[c], lia, lidet, ls2, w * A0[c] - mc - theta - nu, w * B0[c] - mc + theta + nu,
                      pm, dd, cc, s1);
             } else {
-                double pc;
-                const TabRef tb = tab_ref(v, it.node, tbase + c);
-                eval_lines(tb, hint[c], w, iw, mc, pm, A0[c], B0[c], nu, dd, cc, s1, pc);
+                const EvalOut o = eval_lines_call(v.self, it.node, tbase + c, hint[c], mc, pm, A0[c], B0[c], nu);
+                dd = o.dd; cc = o.cc; s1 = o.s1; hint[c] = o.hint;
             }
         };
         // the four prices at which D or C of step c would leave a bound with the step's net injection (hence Psi)
@@ -1199,7 +1216,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
             } else {
                 double pc;
                 if (lin[c]) pc = lp0[c] + lkap[c] * ((dd - cc) - (A0[c] - B0[c]));
-                else pc = tab_psi_at(tab_ref(v, it.node, tbase + c), (dd - cc) - (A0[c] - B0[c]));
+                else pc = tab_psi_call(v.self, it.node, tbase + c, (dd - cc) - (A0[c] - B0[c]));
                 bD = w * A0[c] - mc - pc; bC = mc - w * B0[c] - pc;
             }
         };
@@ -1471,7 +1488,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
                         } else if (kind[c] != 0 && STARTS(c) && bs[c] == TGT(c)) {
                             // idle on a bound: with D = C = 0 the step's net injection is unchanged at q = 0: dlt = -q0
                             const double q0 = A0[c] - B0[c];
-                            const double theta = lin[c] ? lp0[c] - lkap[c] * q0 : tab_psi_at(tab_ref(v, it.node, t), -q0);
+                            const double theta = lin[c] ? lp0[c] - lkap[c] * q0 : tab_psi_call(v.self, it.node, t, -q0);
                             const double rD0 = w * A0[c] - mc - theta, rC0 = w * B0[c] - mc + theta;
                             if (rD0 <= -rC0 && nuv[c] >= rD0 - 1e-9 && nuv[c] <= -rC0 + 1e-9) { mlo[c] = rD0; mhi[c] = -rC0; }
                         }
@@ -1600,8 +1617,11 @@ __device__ __attribute__((noinline)) void sto_cold_lines_call(const DevView *sel
     sto_cold_body<LPS, NCH, true>(*self, blk, left);
 }
 
+#ifndef DOPF_WARM_WAVES
+#define DOPF_WARM_WAVES 2
+#endif
 template <int LPS, int NCH, bool LINES>
-__global__ __launch_bounds__(256, 2) void k_sto_warm(DevView v)
+__global__ __launch_bounds__(256, DOPF_WARM_WAVES) void k_sto_warm(DevView v)
 {
     if (v.st->halt) return;
     const int left = sto_warm_body<LPS, NCH, LINES>(v, blockIdx.x);         // ends on a __syncthreads
