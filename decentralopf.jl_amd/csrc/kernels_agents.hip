@@ -1578,16 +1578,22 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
 #undef DOPF_TOC
 
     // fixed-order block reduction of the per-timestep sums over the NG groups
-    __syncthreads();
+    // the block's sums with ONE barrier: cost and the count of storages left over are added inside each wave first
+    // (butterfly: a fixed order), the four waves then in order. (A lane group's slice of red[] is its own nuL region:
+    // nothing of another wave's is overwritten here. The barrier below waits for LDS traffic only — __syncthreads()
+    // would add the acknowledgement of the rows just stored to the chain.)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) red[(grp * LPS + li) * NCH + c] = accQ[c];
-    redc[tid] = accCost;
-    __shared__ int failCount;
-    if (tid == 0) failCount = 0;
-    __syncthreads();
-    if (anyFail) atomicAdd(&failCount, anyFail);     // integer: order does not matter
-    __syncthreads();
-    const int blockFail = failCount;                 // storages of this item left to the scan kernel
+    __shared__ double wcostS[4];
+    __shared__ int wfailS[4];
+    {
+        double cw = accCost;
+        int fw = anyFail;
+        for (int d = 32; d > 0; d >>= 1) { cw += __shfl_xor(cw, d); fw += __shfl_xor(fw, d); }
+        if (lane == 0) { wcostS[tid >> 6] = cw; wfailS[tid >> 6] = fw; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int blockFail = wfailS[0] + wfailS[1] + wfailS[2] + wfailS[3];     // storages of this item left to the scan kernel
     if (grp == 0) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -1599,11 +1605,8 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
             }
         }
     }
-    for (int sft = 128; sft > 0; sft >>= 1) {
-        if (tid < sft) redc[tid] += redc[tid + sft];
-        __syncthreads();
-    }
-    if (tid == 0) { v.part_scost_w[blk] = redc[0]; v.item_fail[blk] = blockFail; }
+    if (tid == 0) { v.part_scost_w[blk] = ((wcostS[0] + wcostS[1]) + wcostS[2]) + wcostS[3]; v.item_fail[blk] = blockFail; }
+    __syncthreads();                                 // (callers rely on the body ending on a barrier)
     { const int rep = 0, round = 0; DOPF_STAMP(6) }
     return blockFail;
 }
