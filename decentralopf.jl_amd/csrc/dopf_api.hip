@@ -340,6 +340,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         if (const char *e = getenv("DOPF_GEN_BLOCKS")) nb = atoi(e);          // (experiments)
         v.genBlocks = std::min(v.nGenItems, std::max(nb, 192));
     }
+    v.genRows = v.genBlocks;
     {
         // level-1 reduce blocks per node: ~16 items per block, at most 64 (and N*RB blocks in total)
         int max_items = 1;

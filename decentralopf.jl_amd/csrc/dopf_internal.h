@@ -48,6 +48,7 @@ struct DevView {
     int maxNodeAgents;              // most agents (generators + storages) at one node
     int nGenItems, nStoItems;
     int genTT, genR;                // generator block tiling: TT = min(T, 512) timesteps x R agents
+    int genRows;                    // > 0: (one node) the generators' partial sums are this many rows, one per streaming block, not one per item
     int genBlocks;                  // > 0 (needs genChunk): the fused launch has this many generator blocks, each walking items b, b + genBlocks, ...
     int debugLeave;                 // DOPF_F_DEBUG_LEAVE (tests)
     int coldInWarm;                 // networks: k_sto_warm calls the scan body itself for what it leaves over (no k_sto_update launch)

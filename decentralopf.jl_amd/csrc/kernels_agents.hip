@@ -243,15 +243,16 @@ __device__ __forceinline__ void gen_pair_body(const DevView &v, const int blk)
 // launched one per item each of them spent 3.7 us mostly waiting on its one batch of loads (390 of 1516 items done
 // when the storage blocks retired, 2.5 TB/s); streaming, the same 200 blocks keep two batches in flight per lane
 // (3.3 TB/s next to the storage blocks, 5.3 TB/s alone) and finish 3 us after the last storage block instead of 7.
-// Static assignment: every block ends after its last item, and the partial sums stay per ITEM (fixed order, bitwise
-// reproducible whichever block computes them). (Tried: items drawn from a counter so that blocks starting late can help
+// Static assignment: every block ends after its last item; a block always walks the same items in the same order, so
+// its sums run over ALL its items in registers and meet once, at the block's end (one partial row per BLOCK: fixed
+// order, bitwise reproducible; no LDS traffic or barrier inside the loop). (Tried: items drawn from a counter so that blocks starting late can help
 // — a same-address device-scope atomic per item costs more than it balances on eight L2s: 26 vs 21 us.)
 template <int BS>
 __device__ __forceinline__ void gen_pair_stream(const DevView &v, const int first, const int stride)
 {
     constexpr int GU = kGenStreamRows;
-    __shared__ double red[2][2][BS];
-    __shared__ double wc[2][BS / 64];
+    __shared__ double red[2][BS];
+    __shared__ double wc[BS / 64];
     const int halt = v.st->halt;                             // (in flight with the loads below)
     const int T = v.T, N = v.N, TT = v.genTT2, R = v.genR2, nI = v.nGenItems, chunk = v.genChunk, G = v.G;
     const int tid = threadIdx.x;
@@ -281,10 +282,9 @@ __device__ __forceinline__ void gen_pair_stream(const DevView &v, const int firs
             p[u] = P2[(size_t)g_ * half + tt];                                              \
         }                                                                                   \
     }
-#define DOPF_GEN_WORK(item, p, mc, pm, par)                                                 \
+#define DOPF_GEN_WORK(item, p, mc, pm)                                                      \
     {                                                                                       \
         const int a0_ = (item) * chunk, a1_ = min(G, a0_ + chunk);                          \
-        double acc0 = 0.0, acc1 = 0.0, cost = 0.0;                                          \
         _Pragma("unroll") for (int u = 0; u < GU; ++u) {                                    \
             const int g_ = a0_ + r + u * R;                                                 \
             const bool mine = rowlane && g_ < a1_;                                          \
@@ -297,23 +297,23 @@ __device__ __forceinline__ void gen_pair_stream(const DevView &v, const int firs
                 cost = fma(mc[u], pn.x + pn.y, cost);                                       \
             }                                                                               \
         }                                                                                   \
-        /* two LDS buffers in turn: a lane may be one barrier ahead of the slowest reader */ \
-        gen_pair_sums<BS, true>(v, (item), tid, r, tt, acc0, acc1, cost, red[par], wc[par]); \
     }
+    double acc0 = 0.0, acc1 = 0.0, cost = 0.0;
     int i = first;
     DOPF_GEN_LOAD(i, pa, mca, pma)
     for (;;) {
         const int j = i + stride;
         DOPF_GEN_LOAD(min(j, nI - 1), pb, mcb, pmb)
         if (halt) return;                                    // (uniform) nothing is stored in a halted state
-        DOPF_GEN_WORK(i, pa, mca, pma, 0)
+        DOPF_GEN_WORK(i, pa, mca, pma)
         if (j >= nI) break;
         const int k = j + stride;
         DOPF_GEN_LOAD(min(k, nI - 1), pa, mca, pma)
-        DOPF_GEN_WORK(j, pb, mcb, pmb, 1)
+        DOPF_GEN_WORK(j, pb, mcb, pmb)
         if (k >= nI) break;
         i = k;
     }
+    gen_pair_sums<BS>(v, first, tid, r, tt, acc0, acc1, cost, red, wc);       // row `first` of the partials = this block
 #undef DOPF_GEN_LOAD
 #undef DOPF_GEN_WORK
 }

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
         const int tcx = blockIdx.x % TC, nrb = blockIdx.x / TC;
         const int n = nrb / RB, rb = nrb - n * RB;
         const int r = tid >> 5, tt = tid & 31, t = tcx * TT + tt;
-        const int g0 = v.node_gitem_beg[n], ngi = v.node_gitem_beg[n + 1] - g0;
+        const int g0 = v.node_gitem_beg[n], ngi = v.genRows > 0 ? v.genRows : v.node_gitem_beg[n + 1] - g0;    // (genRows: one node)
         const int s0 = v.node_sitem_beg[n], nsi = v.node_sitem_beg[n + 1] - s0;
         // rows to add: generator items, then the storage items' scan partials, then their warm-start partials
         const int ni = ngi + 2 * nsi;
@@ -392,11 +392,12 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
         }
         // cost partials ride with the first node's slices of the first timestep chunk
         if (n == 0 && tcx == 0) {
-            const int nc = v.nGenItems + v.nStoItems, cper = (nc + RB - 1) / RB;
+            const int ngr = v.genRows > 0 ? v.genRows : v.nGenItems;
+            const int nc = ngr + v.nStoItems, cper = (nc + RB - 1) / RB;
             const int c0 = rb * cper, c1 = min(nc, c0 + cper);
             double c = 0.0;
             for (int i = c0 + tid; i < c1; i += 256)
-                c += i < v.nGenItems ? v.part_gcost[i] : v.part_scost[i - v.nGenItems] + v.part_scost_w[i - v.nGenItems];
+                c += i < ngr ? v.part_gcost[i] : v.part_scost[i - ngr] + v.part_scost_w[i - ngr];
             c = block_sum256(c, red);
             if (tid == 0) {
                 if (direct) v.cons[(size_t)N * T + 2 * (size_t)L * T] = c;
