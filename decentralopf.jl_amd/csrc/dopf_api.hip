@@ -48,6 +48,20 @@ int dev_alloc(dopf_ctx *c, Tp **out, size_t n, bool zero = true)
 {
     void *p = nullptr;
     const size_t bytes = std::max<size_t>(n, 1) * sizeof(Tp);
+    static const bool guard = getenv("DOPF_GUARD") != nullptr;
+    if (guard) {
+        // debugging aid: every array ends on a 2 MiB boundary of its own allocation, so that an access past its end leaves
+        // the mapping at once (GPU memory fault at an address that names the array: the ranges are printed)
+        const size_t two = 2u << 20, b16 = (bytes + 15) & ~(size_t)15, tot = (b16 + two - 1) / two * two;
+        HIPCHK(c, hipMalloc(&p, tot));
+        c->allocs.push_back(p);
+        char *q = (char *)p + (tot - b16);
+        static const bool chatty = atoi(getenv("DOPF_GUARD")) > 1;
+        if (chatty) fprintf(stderr, "dopf guard: ctx %p alloc #%zu %zu bytes [%p, %p) base %p\n", (void *)c, c->allocs.size(), bytes, (void *)q, (void *)(q + b16), p);
+        if (zero) HIPCHK(c, hipMemsetAsync(q, 0, bytes, c->main));
+        *out = (Tp *)q;
+        return DOPF_OK;
+    }
     HIPCHK(c, hipMalloc(&p, bytes));
     c->allocs.push_back(p);
     if (zero) HIPCHK(c, hipMemsetAsync(p, 0, bytes, c->main));

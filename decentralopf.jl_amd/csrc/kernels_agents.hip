@@ -13,6 +13,12 @@
 // (the agent loop of Result(...), src/structures/results.jl:72-106) in a fixed order.
 #include "dopf_internal.h"
 
+#ifdef DOPF_INLINE_CALLS
+#define DOPF_CALL_ATTR __forceinline__
+#else
+#define DOPF_CALL_ATTR __attribute__((noinline))
+#endif
+
 namespace dopf {
 
 #if defined(DOPF_STATS) || defined(DOPF_BLOCK_STAMPS)
@@ -617,7 +623,7 @@ __device__ __forceinline__ void eval_lines(const TabRef &tb, int &hint, double w
 // The same two as functions of their own, for the active-set body: there a (node, timestep) with a non-empty table is
 // the rare case (none in the settled state), and inlined their registers cost the common path a wave per SIMD.
 struct EvalOut { double dd, cc, s1, pc; int hint; };
-__device__ __attribute__((noinline)) EvalOut eval_lines_call(const DevView *self, int node, int t, int hint, double mc, double pm,
+__device__ DOPF_CALL_ATTR EvalOut eval_lines_call(const DevView *self, int node, int t, int hint, double mc, double pm,
                                                              double D0, double C0, double nu)
 {
     const DevView &v = *self;
@@ -627,7 +633,7 @@ __device__ __attribute__((noinline)) EvalOut eval_lines_call(const DevView *self
     eval_lines(tb, o.hint, v.w_prox, 1.0 / v.w_prox, mc, pm, D0, C0, nu, o.dd, o.cc, o.s1, o.pc);
     return o;
 }
-__device__ __attribute__((noinline)) double tab_psi_call(const DevView *self, int node, int t, double dl)
+__device__ DOPF_CALL_ATTR double tab_psi_call(const DevView *self, int node, int t, double dl)
 {
     return tab_psi_at(tab_ref(*self, node, t), dl);
 }
@@ -1183,7 +1189,8 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
             const bool ok = live && t < T;
             const size_t e = (size_t)s * T + (ok ? t : 0);
             const double d0 = ok ? v.D[e] : 0.0, c0 = ok ? v.C[e] : 0.0;
-            const double nu_st = v.nu_prev[e];                 // (always loaded: a load behind the nu_valid word would be a second round trip)
+            const double nu_st = v.nu_prev[ok ? e : 0];        // (always loaded — from a valid address: a lane group without a storage
+                                                               // has s past the end — a load behind the nu_valid word would be a second round trip)
             nuv[c] = (ok && havenu) ? nu_st : 0.0;             // no stored prices (zero state, set_state): start from 0
             hint[c] = 0;
             run += c0 - d0;
@@ -1615,7 +1622,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
 // something of. Inlined, its registers crowd the active-set body (255 VGPRs and spills, 40 % slower, measured); as a
 // separate launch it cost 4 us + a launch gap per iteration for finding nothing to do.
 template <int LPS, int NCH>
-__device__ __attribute__((noinline)) void sto_cold_lines_call(const DevView *self, const int blk, const int left)
+__device__ DOPF_CALL_ATTR void sto_cold_lines_call(const DevView *self, const int blk, const int left)
 {
     sto_cold_body<LPS, NCH, true>(*self, blk, left);
 }

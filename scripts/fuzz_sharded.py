@@ -6,9 +6,11 @@ import numpy as np, torch, dopf_pkg
 pkg = dopf_pkg.load()
 from decentralopf_jl_amd import _capi, synth
 from helpers import make_engine, state_of
-hip = _capi.hip_api()
+hip = _capi.CApi(os.environ["DOPF_LIB"], "dopf_") if os.environ.get("DOPF_LIB") else _capi.hip_api()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+start = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # (replay: draw the first cases without running them)
+verbose = len(sys.argv) > 4
 worst_all, bad = 0.0, 0
 t0 = time.time()
 for k in range(n_cases):
@@ -27,13 +29,18 @@ for k in range(n_cases):
     A = G + S
     K = int(rng.integers(2, 5))
     params = dict(gamma=float(rng.choice([1.0, 0.3])) / A, w_flow=(0.1 / A if net else 10.0), eps=0.0)
+    iters = int(rng.integers(5, 40))
+    if k < start:
+        continue
+    if verbose:
+        print(k, case, 'shards', K, params, 'iters', iters, flush=True)
     ref = make_engine(hip, pp, **params)
     engs = [make_engine(hip, pp.shard(r, K), n_agents_global=A, **params) for r in range(K)]
     bufs = [torch.zeros(e.consensus_size(), dtype=torch.float64, device="cuda") for e in engs]
     for e, b in zip(engs, bufs):
         e.bind_consensus(b.data_ptr())
-    iters = int(rng.integers(5, 40))
-    for _ in range(iters):
+    for it_ in range(iters):
+        if verbose: print('  it', it_, flush=True)
         for e in engs: e.local_update()
         for e in engs: e.sync()
         total = sum(bufs[1:], bufs[0].clone())
@@ -41,9 +48,15 @@ for k in range(n_cases):
         torch.cuda.synchronize()
         for e in engs: e.apply_consensus()
         for e in engs: e.sync()
+    if verbose: print('  loop done', flush=True)
     ref.iterate(iters)
+    if verbose: print('  ref done', flush=True)
     want = state_of(ref)
-    got = [state_of(e) for e in engs]
+    if verbose: print('  ref state', flush=True)
+    got = []
+    for e in engs:
+        got.append(state_of(e))
+        if verbose: print('  shard state', len(got), flush=True)
     w = 0.0
     for key in ("lam", "mu", "rho", "inj", "flow"):
         if want[key].size:

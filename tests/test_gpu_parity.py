@@ -540,3 +540,15 @@ def test_hand_over_from_the_active_set_body_to_the_scan_body(hip_api, shape):
             if a[key].size:
                 assert np.abs(a[key] - b[key]).max() <= 1e-8 * max(1.0, np.abs(b[key]).max()), (shape, key, k)
     assert e.solver_failures() == 0
+
+
+def test_no_access_past_the_end_of_any_device_array(hip_api):
+    """DOPF_GUARD=1 puts every device array at the end of its own mapping: an access past an array's end kills the process
+    with a GPU memory fault instead of reading a neighbour. Ragged shapes, shards and whole runs in a child process
+    (tests/guard_worker.py; the first case is the one scripts/fuzz_sharded.py tripped over in round 2)."""
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "guard_worker.py")
+    r = subprocess.run([sys.executable, worker], env=dict(os.environ, DOPF_GUARD="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "guard worker: ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
