@@ -368,13 +368,25 @@ __device__ __forceinline__ void gen_pair_skip_body(const DevView &v, const int b
     double2 *P2 = reinterpret_cast<double2 *>(v.P);
     const size_t half = (size_t)(T >> 1);
     const int nPass = (it.a1 - it.a0 + R - 1) / R;
+    // the row's state word and parameters are fetched one pass ahead: the decision "sweep or skip" then costs no round
+    // trip of its own in front of the row load (a valid row is read when the lane has none: straight-line, dropped)
+    double mcN, pmN;
+    int sttN;
+    {
+        const int g0_ = it.a0 + r < it.a1 && r < R ? it.a0 + r : it.a0;
+        mcN = v.gen_mc[g0_]; pmN = v.gen_pmax[g0_]; sttN = v.gen_state[g0_];
+    }
     for (int p = 0; p < nPass; ++p) {
         const int g = it.a0 + p * R + r;
         const bool on = r < R && g < it.a1;
         bool full = false;
+        const double mc = mcN, pm = pmN;
+        const int stt = sttN;                               // 0 all zero, 1 all at pmax, 2 mixed
+        {
+            const int gn_ = g + R < it.a1 && r < R ? g + R : it.a0;
+            mcN = v.gen_mc[gn_]; pmN = v.gen_pmax[gn_]; sttN = v.gen_state[gn_];
+        }
         if (on) {
-            const double mc = v.gen_mc[g], pm = v.gen_pmax[g];
-            const int stt = v.gen_state[g];                 // 0 all zero, 1 all at pmax, 2 mixed
             // fma(mc, inv, .) is monotone in its addend, so its extremes over t are at smin / smax
             if (stt == 0 && fma(mc, inv, smin) >= 0.0) {
                 // stays all zero: nothing to read, write or add
