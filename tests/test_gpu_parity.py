@@ -73,6 +73,7 @@ SYNTH = [
     ("net-4x3-noise-level-ptdf-entries", dict(n_gen=31, n_sto=0, T=30, N=4, L=3, seed=153374, fmax_factor=0.5, fmax_min=1.0), dict(gamma=0.03225806451612903, w_flow=0.1), 0, 6, 1e-6),
     ("net-6x5-storages-w0.1", dict(n_gen=15, n_sto=22, T=8, N=6, L=5, seed=866744, fmax_factor=0.8, fmax_min=1.0), dict(gamma=0.05, w_flow=0.1), 1, 12, 1e-8),
     ("storages-only", dict(n_gen=0, n_sto=12, T=24, seed=14), dict(gamma=0.05), 1, 10, 1e-9),
+    ("net-100x300-more-lines-than-one-block (k_dual_t + k_price_t)", dict(n_gen=150, n_sto=20, T=24, N=100, L=300, seed=23, fmax_factor=0.7, fmax_min=20), dict(gamma=0.01), 1, 4, 1e-7),
     ("net-118x186-config3-shape", dict(n_gen=900, n_sto=90, T=12, N=118, L=186, seed=19, fmax_factor=0.7, fmax_min=20), dict(gamma=0.002), 1, 4, 1e-7),
 ]
 
