@@ -17,9 +17,12 @@ synthetic network, 100k agents x 168.
 
 --gpus N > 1 without a torch.distributed.run environment: this process starts the N ranks itself (children,
 one per GPU, before anything here touches the GPU) and relays rank 0's line. Every rank holds one full grid
-(weak scaling); the per-iteration consensus sum is ONE RCCL all-reduce issued by the library itself
-(dopf_comm_init: captured with the kernels in the iteration's hipGraph), `--comm torch` keeps the older path
-where torch.distributed issues it between two library calls.
+(weak scaling); the per-iteration sum of the consensus vector over the ranks is done inside the library: `--comm p2p`
+the peer exchange (one kernel of the iteration graph stores the vector into every peer's memory over xGMI and adds the
+copies in rank order), `--comm lib` an RCCL all-reduce issued by the library, `--comm torch` the older path where
+torch.distributed issues it between two library calls. `--comm auto` (default) tries them in that order: a transport
+that raises, leaves the ranks with different duals, fails the host-side check of the summed injections or fails in the
+timed region is given up in place and named in the line (`comm.transports_given_up`).
 """
 import argparse
 import json
