@@ -22,7 +22,10 @@ using namespace dopf;
 
 namespace {
 
-constexpr int kUnroll = 16, kMid = 4;
+#ifndef DOPF_UNROLL
+#define DOPF_UNROLL 16
+#endif
+constexpr int kUnroll = DOPF_UNROLL, kMid = 4;
 constexpr int kCheckEvery = 512;
 thread_local char g_create_err[512];
 
