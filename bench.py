@@ -624,27 +624,28 @@ def main():
             ex.close()
             out["also"] = also
             # BASELINE configs[4] asks for a penalty sweep on the 1M-agent grid: iterations / seconds to the 1e-3 residual
-            pp4 = make_problem(synth, "config4")
-            A4 = pp4.G + pp4.S
-            sweep = []
-            for m in (0.3, 1.0, 1.5, 3.0):
-                cap = 2500
-                ex = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=m / A4, eps=1e-3, max_iters=cap, device=local_rank),
-                                  **pp4.engine_kwargs())
-                ex.iterate(0)
-                clock_warm()
-                t0 = time.perf_counter()
-                dn, cv = 0, False
-                while not cv and dn < cap:
-                    d_, cv = ex.iterate(min(64, cap - dn))
-                    dn += d_
-                    if d_ == 0:
-                        break
-                tx = time.perf_counter() - t0
-                sweep.append({"gamma_times_A": m, "iterations": dn, "converged": bool(cv), "seconds": tx, "iters_per_sec": dn / tx})
-                ex.close()
-            out["config4_penalty_sweep"] = {"agents": A4, "timesteps": pp4.T, "stop_test": "all |dual change| < 1e-3", "iteration_cap": 2500,
-                                            "rows": sweep}
+            # (the same on the headline workload: where the bench's gamma = 1/A sits in its convergent range)
+            def penalty_sweep(ppx, values, cap):
+                Ax, rows = ppx.G + ppx.S, []
+                for m in values:
+                    ex_ = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=m / Ax, eps=1e-3, max_iters=cap, device=local_rank),
+                                       **ppx.engine_kwargs())
+                    ex_.iterate(0)
+                    clock_warm()
+                    t0_ = time.perf_counter()
+                    dn, cv = 0, False
+                    while not cv and dn < cap:
+                        d_, cv = ex_.iterate(min(64, cap - dn))
+                        dn += d_
+                        if d_ == 0:
+                            break
+                    tx_ = time.perf_counter() - t0_
+                    rows.append({"gamma_times_A": m, "iterations": dn, "converged": bool(cv), "seconds": tx_, "iters_per_sec": dn / tx_})
+                    ex_.close()
+                return {"agents": Ax, "timesteps": ppx.T, "stop_test": "all |dual change| < 1e-3", "iteration_cap": cap, "rows": rows}
+            out["config4_penalty_sweep"] = penalty_sweep(make_problem(synth, "config4"), (0.3, 1.0, 1.5, 3.0), 2500)
+            if args.workload == "config2":
+                out["config2_penalty_sweep"] = penalty_sweep(pp, (0.3, 1.0, 1.5, 2.0), 2000)
         if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pp, gamma, w_flow, synth)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
