@@ -1116,14 +1116,17 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
             const double rl = fabs(ln - lam_old);
             const double bm = fmax(fmax(wmx[0][0], wmx[0][1]), fmax(wmx[0][2], wmx[0][3]));
             const double br = fmax(fmax(wmx[1][0], wmx[1][1]), fmax(wmx[1][2], wmx[1][3]));
-            if (rl > 0.0) atomic_max_pos(&v.st->resbits[0], rl);
-            if (bm > 0.0) atomic_max_pos(&v.st->resbits[1], bm);
-            if (br > 0.0) atomic_max_pos(&v.st->resbits[2], br);
+            // Nothing but the three maxima travels from the other blocks to the last one, and they travel in device-scope
+            // atomics (performed at the memory side, past the per-XCD L2s). So no release fence — that would write this
+            // XCD's whole L2 back — only: the maxima have RETURNED before the ticket is drawn.
+            unsigned long long r0_ = 0, r1_ = 0, r2_ = 0;
+            if (rl > 0.0) r0_ = atomicMax(&v.st->resbits[0], (unsigned long long)__double_as_longlong(rl));
+            if (bm > 0.0) r1_ = atomicMax(&v.st->resbits[1], (unsigned long long)__double_as_longlong(bm));
+            if (br > 0.0) r2_ = atomicMax(&v.st->resbits[2], (unsigned long long)__double_as_longlong(br));
             if (t == 0) v.st->total_cost = v.cons[NT + 2 * LT];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(r0_), "v"(r1_), "v"(r2_) : "memory");
             const int last = atomicAdd(v.dual_ticket, 1) == T - 1;
             if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 Status *st = v.st;
                 const double r0 = __longlong_as_double((long long)__hip_atomic_load(&st->resbits[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 const double r1 = __longlong_as_double((long long)__hip_atomic_load(&st->resbits[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
