@@ -1077,6 +1077,16 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
     const int anyNeed = wany[0] | wany[1] | wany[2] | wany[3];
     const int nz = wnz[0] | wnz[1] | wnz[2] | wnz[3];
     const bool lin = !anyNeed;
+    // residual maxima of this timestep: issued here, they return while the price half runs (see the ticket at the end)
+    unsigned long long r0_ = 0, r1_ = 0, r2_ = 0;
+    if (UPDATE && tid == 0) {
+        const double rl = fabs(ln - lam_old);
+        const double bm = fmax(fmax(wmx[0][0], wmx[0][1]), fmax(wmx[0][2], wmx[0][3]));
+        const double br = fmax(fmax(wmx[1][0], wmx[1][1]), fmax(wmx[1][2], wmx[1][3]));
+        if (rl > 0.0) r0_ = atomicMax(&v.st->resbits[0], (unsigned long long)__double_as_longlong(rl));
+        if (bm > 0.0) r1_ = atomicMax(&v.st->resbits[1], (unsigned long long)__double_as_longlong(bm));
+        if (br > 0.0) r2_ = atomicMax(&v.st->resbits[2], (unsigned long long)__double_as_longlong(br));
+    }
 
     // ---- price half: thread (line part pp, node n) -------------------------------------------------------------
     const int NP = N <= 128 ? 128 : 256, P = 1024 / NP;
@@ -1113,16 +1123,9 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
     if (UPDATE) {
         // residual maxima of this timestep, then the ticket: whoever is last has every block's maxima behind it
         if (tid == 0) {
-            const double rl = fabs(ln - lam_old);
-            const double bm = fmax(fmax(wmx[0][0], wmx[0][1]), fmax(wmx[0][2], wmx[0][3]));
-            const double br = fmax(fmax(wmx[1][0], wmx[1][1]), fmax(wmx[1][2], wmx[1][3]));
             // Nothing but the three maxima travels from the other blocks to the last one, and they travel in device-scope
             // atomics (performed at the memory side, past the per-XCD L2s). So no release fence — that would write this
             // XCD's whole L2 back — only: the maxima have RETURNED before the ticket is drawn.
-            unsigned long long r0_ = 0, r1_ = 0, r2_ = 0;
-            if (rl > 0.0) r0_ = atomicMax(&v.st->resbits[0], (unsigned long long)__double_as_longlong(rl));
-            if (bm > 0.0) r1_ = atomicMax(&v.st->resbits[1], (unsigned long long)__double_as_longlong(bm));
-            if (br > 0.0) r2_ = atomicMax(&v.st->resbits[2], (unsigned long long)__double_as_longlong(br));
             if (t == 0) v.st->total_cost = v.cons[NT + 2 * LT];
             asm volatile("s_waitcnt vmcnt(0)" ::"v"(r0_), "v"(r1_), "v"(r2_) : "memory");
             const int last = atomicAdd(v.dual_ticket, 1) == T - 1;
