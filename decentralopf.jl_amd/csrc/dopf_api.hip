@@ -361,7 +361,8 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     {
         // level-1 reduce blocks per node: ~16 items per block, at most 64 (and N*RB blocks in total)
         int max_items = 1;
-        for (int n = 0; n < N; ++n) max_items = std::max(max_items, (ngib[n + 1] - ngib[n]) + 2 * (nsib[n + 1] - nsib[n]));   // storage items: scan + warm rows
+        for (int n = 0; n < N; ++n)      // storage items: scan + warm rows; generators: items, or (one node, streaming) blocks
+            max_items = std::max(max_items, (v.genRows > 0 ? v.genRows : ngib[n + 1] - ngib[n]) + 2 * (nsib[n + 1] - nsib[n]));
         v.reduceRB = std::max(1, std::min(64, (max_items + 31) / 32));
     }
 
