@@ -117,3 +117,30 @@ def test_export_results_on_hip_matches_reference_dump(three_node, golden, tmp_pa
     r = admm.results[-1].of(gens[0])
     assert r.U.shape == (3, 2) and r.K.shape == (3, 2) and r.penalty_term.energy_balance.shape == (2,)
     assert len(admm.convergence.lambda_res) == 11 and admm.convergence.mue_res[-1].shape == (3, 2)
+
+
+def test_bench_line_keeps_the_driver_contract(tmp_path):
+    """`python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with the keys the driver and the judge read
+    (metric/value/unit/n_gpus/steps/warmup/ms_per_step/..., roofline, config) — here on the small workload, side runs off."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "3",
+                        "--workload", "config1", "--no-also", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["metric"] == "agent_subproblem_updates_per_sec" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 3
+    assert d["dtype"] == "f64" and d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["config"]["workload"] == "config1" and "model" not in d["config"]
+    ro = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in ro, k
+    assert ro["bound"] == "hbm" and ro["peak"] == 8000.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
+    assert abs(d["value"] - d["config"]["agents_per_gpu"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
