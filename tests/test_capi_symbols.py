@@ -53,12 +53,12 @@ def test_no_cpu_fallback_in_product_package():
                 assert "oracle_create" not in text and "ORACLE_LIB" not in text, f
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, name="three_node"):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib_dir = os.path.join(root, "decentralopf.jl_amd", "csrc")
-    exe = str(tmp_path / "three_node")
-    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "three_node.c"),
+    exe = str(tmp_path / name)
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", name + ".c"),
                     "-o", exe, "-L" + lib_dir, "-ldopf_hip", "-Wl,-rpath," + lib_dir], check=True)
     return exe
 
@@ -72,6 +72,8 @@ def test_c_example_builds_against_the_abi_and_fails_loudly_without_a_gpu(tmp_pat
         pytest.skip("GPU present: covered by the gpu-marked test")
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 1 and "no CPU fallback" in r.stderr
+    r = subprocess.run([_build_c_example(tmp_path, "three_node_multi")], capture_output=True, text=True)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr
 
 
 @pytest.mark.gpu
@@ -82,4 +84,17 @@ def test_c_example_reproduces_the_reference_run(tmp_path):
     assert r.returncode == 0, r.stderr
     assert "converged after 476 iterations, total cost 14034.51" in r.stdout
     assert "t=1 nodal prices -36.597 -15.216 -30.000" in r.stdout           # thesis Table 17 (tests/golden/thesis_tables.json)
+    assert "t=2 nodal prices -81.976 -4.013 -30.000" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards", [1, 2, 3])
+def test_c_example_sharded_run_equals_the_reference_run(tmp_path, shards):
+    """examples/three_node_multi.c: dopf_multi_* with the peer exchange from plain C (all shards on device 0 here)."""
+    import subprocess
+    r = subprocess.run([_build_c_example(tmp_path, "three_node_multi"), str(shards)], capture_output=True, text=True,
+                       env=dict(os.environ, DOPF_XCHG_TIMEOUT_MS="5000"))
+    assert r.returncode == 0, r.stderr
+    assert "converged after 476 iterations, total cost 14034.51 (%d shards)" % shards in r.stdout
+    assert "t=1 nodal prices -36.597 -15.216 -30.000" in r.stdout
     assert "t=2 nodal prices -81.976 -4.013 -30.000" in r.stdout
