@@ -1193,6 +1193,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
         // (with lines Psi depends on the step itself: D0/C0 are kept and the offsets are built per evaluation)
         double A0[NCH], B0[NCH], nuv[NCH];       // (rD0, rC0) without lines, (D0, C0) with
         int hint[NCH];
+        double dq[NCH];                          // C0 - D0 per step: the level trajectory below needs only these
         const double iw = 1.0 / w;
         double run = 0.0;
 #pragma unroll
@@ -1205,6 +1206,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
                                                                // has s past the end — a load behind the nu_valid word would be a second round trip)
             nuv[c] = (ok && havenu) ? nu_st : 0.0;             // no stored prices (zero state, set_state): start from 0
             hint[c] = 0;
+            dq[c] = c0 - d0;
             run += c0 - d0;
             if (LINES) { A0[c] = d0; B0[c] = c0; }
             else {
@@ -1244,16 +1246,12 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
         const double prevE = prev_lane<LPS>(inclE);
         const double tolc = 1e-9 * (1.0 + em), tolE = 1e-11 * (1.0 + em), tolr = 1e-12 * (1.0 + em);
         int kind[NCH];                       // 0 free, 1 empty, 2 full
-        // (levels need D0, C0 themselves: re-read them — L1 hits — instead of keeping two more arrays alive)
         {
             double eo = li == 0 ? 0.0 : prevE;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int t = tbase + c;
-                const bool ok = live && t < T;
-                const size_t e = (size_t)s * T + (ok ? t : 0);
-                const double d0 = LINES ? A0[c] : (ok ? v.D[e] : 0.0), c0 = LINES ? B0[c] : (ok ? v.C[e] : 0.0);
-                eo += c0 - d0;
+                eo += dq[c];
                 kind[c] = t < T ? (eo <= tolc ? 1 : (eo >= em - tolc ? 2 : 0)) : 0;
             }
         }
