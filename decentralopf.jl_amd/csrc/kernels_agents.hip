@@ -693,10 +693,13 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
         lin[c] = false; lp0[c] = 0.0; lkap[c] = 0.0;
         if (LINES && t < T) {
             const size_t at = (size_t)it.node + (size_t)N * t;
-            if (v.tb_m[at] == 0) {
+            // (all three loaded at once: the size word in front of the other two would be a round trip of its own)
+            const int m_ = v.tb_m[at];
+            const double p0_ = v.tb_psi0[at], k_ = v.tb_slope[at * (v.M2 + 1)];
+            if (m_ == 0) {
                 lin[c] = true;
-                lp0[c] = v.tb_psi0[at];
-                lkap[c] = v.tb_slope[at * (v.M2 + 1)];
+                lp0[c] = p0_;
+                lkap[c] = k_;
             }
         }
     }
@@ -1167,10 +1170,13 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
         lin[c] = false; lp0[c] = 0.0; lkap[c] = 0.0;
         if (LINES && t < T) {
             const size_t at = (size_t)it.node + (size_t)N * t;
-            if (v.tb_m[at] == 0) {
+            // (all three loaded at once: the size word in front of the other two would be a round trip of its own)
+            const int m_ = v.tb_m[at];
+            const double p0_ = v.tb_psi0[at], k_ = v.tb_slope[at * (v.M2 + 1)];
+            if (m_ == 0) {
                 lin[c] = true;
-                lp0[c] = v.tb_psi0[at];
-                lkap[c] = v.tb_slope[at * (v.M2 + 1)];
+                lp0[c] = p0_;
+                lkap[c] = k_;
             }
         }
     }
