@@ -746,16 +746,34 @@ __device__ __forceinline__ void price_body(const DevView &v, size_t i)
 }
 
 // check_convergence!, convergence.jl:1-31 (one thread)
-__device__ __forceinline__ void status_update(const DevView &v, double r0, double r1, double r2)
+// the status words a stop test starts from: loaded early by callers that can (a load at the very end of a one-block
+// kernel is a round trip on its critical path)
+struct StatusPre { int iteration, converged, iters_total; };
+__device__ __forceinline__ StatusPre status_load(const DevView &v)
+{
+    StatusPre s;
+    s.iteration = v.st->iteration; s.converged = v.st->converged; s.iters_total = v.st->iters_total;
+    return s;
+}
+
+__device__ __forceinline__ void status_update(const DevView &v, const StatusPre s, double r0, double r1, double r2)
 {
     Status *st = v.st;
-    if (st->iteration != 1) {                                             // convergence.jl:3
+    int conv = s.converged, it = s.iteration;
+    if (it != 1) {                                                        // convergence.jl:3
         st->res[0] = r0; st->res[1] = r1; st->res[2] = r2;
-        st->converged = (r0 < v.eps) && (r1 < v.eps) && (r2 < v.eps);
+        conv = (r0 < v.eps) && (r1 < v.eps) && (r2 < v.eps);
+        st->converged = conv;
     }
-    st->iters_total += 1;
-    if (!st->converged) st->iteration += 1;                               // convergence.jl:25-30
-    st->halt = st->converged || (v.max_iters > 0 && st->iteration > v.max_iters);
+    st->iters_total = s.iters_total + 1;
+    if (!conv) it += 1;                                                   // convergence.jl:25-30
+    st->iteration = it;
+    st->halt = conv || (v.max_iters > 0 && it > v.max_iters);
+}
+
+__device__ __forceinline__ void status_update(const DevView &v, double r0, double r1, double r2)
+{
+    status_update(v, status_load(v), r0, r1, r2);
 }
 
 template <bool UPDATE>
@@ -1164,6 +1182,7 @@ __global__ __launch_bounds__(256) void k_dual_price_small(DevView v, XchgView x)
         const int r = tid >> 5, tt = tid & 31;
         __shared__ double injL[256], lamL[256], wmax[4];
         const size_t me = tid;                                // entry n + N*t of this thread in the later stages
+        const StatusPre spre = status_load(v);                // (with the other loads, not behind the last barrier)
         const double dem = me < NT ? v.demand[me] : 0.0;
         const double lam_old = tid < T ? v.lam[tid] : 0.0, s_old = tid < T ? v.s[tid] : 0.0;
         const double cslice = tid < 64 && tid < RB ? v.part2_cost[tid] : 0.0;
@@ -1266,7 +1285,7 @@ __global__ __launch_bounds__(256) void k_dual_price_small(DevView v, XchgView x)
         if ((tid & 63) == 0) wmax[tid >> 6] = rl;
         __syncthreads();
         if (me < NT) v.price[me] = lamL[me / N];              // no lines: the nodal price is lambda
-        if (tid == 0) status_update(v, fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3])), 0.0, 0.0);
+        if (tid == 0) status_update(v, spre, fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3])), 0.0, 0.0);
         return;
     }
     if (UPDATE && v.sliceDual) {
