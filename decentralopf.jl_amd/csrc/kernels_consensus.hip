@@ -346,7 +346,9 @@ __device__ __forceinline__ bool slack_needs_cases(double g, double w2, double in
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_reduce(DevView v)
 {
-    if (v.st->halt) return;
+    // (the halt word is looked at after the loads below have been issued: one round trip, not two; nothing is stored
+    // before that)
+    const int halt = v.st->halt;
     __shared__ double red[256];
     __shared__ int last_sh;
     const int tid = threadIdx.x;
@@ -357,8 +359,11 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
         const int tcx = blockIdx.x % TC, nrb = blockIdx.x / TC;
         const int n = nrb / RB, rb = nrb - n * RB;
         const int r = tid >> 5, tt = tid & 31, t = tcx * TT + tt;
-        const int g0 = v.node_gitem_beg[n], ngi = v.genRows > 0 ? v.genRows : v.node_gitem_beg[n + 1] - g0;    // (genRows: one node)
-        const int s0 = v.node_sitem_beg[n], nsi = v.node_sitem_beg[n + 1] - s0;
+        // (one node: the row ranges are known without the item tables — a round trip less in front of the row loads)
+        const bool one = N == 1;
+        const int g0 = one ? 0 : v.node_gitem_beg[n];
+        const int ngi = v.genRows > 0 ? v.genRows : (one ? v.nGenItems : v.node_gitem_beg[n + 1] - g0);    // (genRows: one node)
+        const int s0 = one ? 0 : v.node_sitem_beg[n], nsi = one ? v.nStoItems : v.node_sitem_beg[n + 1] - s0;
         // rows to add: generator items, then the storage items' scan partials, then their warm-start partials
         const int ni = ngi + 2 * nsi;
         const int per = (ni + RB - 1) / RB;
@@ -381,6 +386,7 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
                 acc += (x[0] + x[1]) + (x[2] + x[3]);
             }
         }
+        if (halt) return;                                   // (uniform)
         red[tid] = acc;
         __syncthreads();
         const bool direct = RB == 1 && !v.sliceDual;       // one slice per node: its sum IS the node's sum
@@ -455,6 +461,7 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
         // 4x the loads in flight of one thread per line walking all N nodes (these are chains of L2-latency-bound ptdf
         // reads) — and the four partial sums meet in LDS, added in part order. The change of every node's injection in
         // this iteration (new minus previous sum of its items' partials) and the nodes' constants are staged in LDS.
+        if (halt) return;
         extern __shared__ double nsh[];               // [N] node changes of timestep t | [N] window | [N] agents at the node
         __shared__ double pred[256];
         double *sdL = nsh, *winL = nsh + N, *naL = nsh + 2 * N;
@@ -1168,7 +1175,7 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
 template <bool UPDATE, bool XCHG>
 __global__ __launch_bounds__(256) void k_dual_price_small(DevView v, XchgView x)
 {
-    if (UPDATE && v.st->halt) return;
+    const int halt = UPDATE ? v.st->halt : 0;              // (looked at once the loads below are on their way)
     __shared__ double red[8][256];
     const int tid = threadIdx.x;
     const size_t NT = (size_t)v.N * v.T, LT = (size_t)v.L * v.T;
@@ -1206,6 +1213,7 @@ __global__ __launch_bounds__(256) void k_dual_price_small(DevView v, XchgView x)
 #pragma unroll
         for (int c = 0; c < 8; ++c) red[c][tid] = sc[c];
         __syncthreads();
+        if (halt) return;                                     // (uniform; nothing has been stored or sent yet)
         double tot = 0.0;
         if (me < NT) {
             const int c = (int)(me >> 5), t5 = (int)(me & 31);
@@ -1288,6 +1296,7 @@ __global__ __launch_bounds__(256) void k_dual_price_small(DevView v, XchgView x)
         if (tid == 0) status_update(v, spre, fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3])), 0.0, 0.0);
         return;
     }
+    if (halt) return;
     if (UPDATE && v.sliceDual) {
         // level 2 of the consensus sum, here instead of behind a ticket in k_reduce: slice order, so the bits are
         // the ones the two-level kernel produces
