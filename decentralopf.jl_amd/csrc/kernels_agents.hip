@@ -1127,7 +1127,7 @@ __device__ __forceinline__ int next_lane_i(int x)
 
 // returns the number of storages of the item left to the scan (block-uniform)
 template <int LPS, int NCH, bool LINES>
-__device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
+__device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, const int halt = 0)
 {
     constexpr int NG = 256 / LPS, TP = LPS * NCH;
     constexpr int MAXR = 16;                 // contact-set rounds per storage
@@ -1145,6 +1145,8 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk)
     Item it;
     if (v.stoChunk > 0) { it.a0 = blk * v.stoChunk; it.a1 = min(v.S, it.a0 + v.stoChunk); it.node = 0; }
     else it = v.sto_items[blk];
+    // `halt`: the caller's halt word, loaded but not yet looked at, so that it travels with the item (uniform; -1 = halted)
+    if (halt) return -1;
     const int T = v.T, N = v.N;
     const double w = v.w_prox, gam = v.gamma;
     const double a0 = w + gam, ia0 = 1.0 / a0, idet0 = 1.0 / (a0 * a0 - gam * gam), s20 = 2.0 / (a0 + gam);
@@ -1649,8 +1651,8 @@ __device__ DOPF_CALL_ATTR void sto_cold_lines_call(const DevView *self, const in
 template <int LPS, int NCH, bool LINES>
 __global__ __launch_bounds__(256, DOPF_WARM_WAVES) void k_sto_warm(DevView v)
 {
-    if (v.st->halt) return;
-    const int left = sto_warm_body<LPS, NCH, LINES>(v, blockIdx.x);         // ends on a __syncthreads
+    const int left = sto_warm_body<LPS, NCH, LINES>(v, blockIdx.x, v.st->halt);         // ends on a __syncthreads
+    if (left < 0) return;                                                               // halted
     if (LINES && v.coldInWarm) {
         if (left == 0) {                         // (what the scan body writes when there is nothing for it)
             for (int t = threadIdx.x; t < v.T; t += 256) v.part_sinj[(size_t)blockIdx.x * v.T + t] = 0.0;
