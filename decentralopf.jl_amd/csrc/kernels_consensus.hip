@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(256) void k_price_t(DevView v)
 template <bool UPDATE>
 __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
 {
-    if (UPDATE && v.st->halt) return;
+    const int halt = UPDATE ? v.st->halt : 0;           // (looked at once the first loads are on their way; nothing stored before)
     extern __shared__ double sh[];               // q[N] injections | d[L] mu - rho | G[L] | S[L]
     __shared__ double red[3][1024];
     __shared__ double wsum[4], wmx[2][4];
@@ -1041,7 +1041,6 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
     if (tid < N) {
         x = cinj[tid + (size_t)N * t] - v.demand[tid + (size_t)N * t];       // results.jl:58-100
         q[tid] = x;
-        v.inj[tid + (size_t)N * t] = x;
     }
     {   // imbalance: butterfly inside each of the (at most four) waves that hold nodes, waves in order
         double ps = x;
@@ -1049,6 +1048,8 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         if (lane == 0 && tid < 256) wsum[tid >> 6] = ps;
     }
     __syncthreads();
+    if (halt) return;                                    // (uniform)
+    if (tid < N) v.inj[tid + (size_t)N * t] = x;
     const double sum = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
     const double ln = UPDATE ? lam_old + g * sum : lam_old;                     // update_duals.jl:8-13
     if (tid == 0) {
