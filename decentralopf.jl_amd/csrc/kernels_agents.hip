@@ -135,21 +135,22 @@ __global__ __launch_bounds__(512) void k_gen_update(DevView v)
                 }
             }
         }
-        // fixed-order reduction over the R agent lanes that share a timestep
+        // fixed-order reduction over the R agent lanes that share a timestep (only LDS data crosses these barriers:
+        // __syncthreads() would also wait for the acknowledgement of the rows just stored)
         red[tid] = acc;
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (r == 0 && t < T) {
             double sum = 0.0;
             for (int q = 0; q < R; ++q) sum += red[q * TT + tt];
             v.part_ginj[(size_t)blockIdx.x * T + t] = sum;
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     // cost: butterfly inside each wave, then the eight waves in order — one barrier instead of one per tree level
     __shared__ double wcost[8];
     for (int d = 32; d > 0; d >>= 1) cost += __shfl_xor(cost, d);
     if ((tid & 63) == 0) wcost[tid >> 6] = cost;
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (tid == 0) {
         double c = 0.0;
         for (int q = 0; q < 8; ++q) c += wcost[q];
