@@ -111,7 +111,10 @@ typedef struct dopf_params {
 #define DOPF_F_COMM_GRAPH   512  /* contexts joined to a communicator of > 1 ranks: capture the RCCL all-reduce into the iteration
                                    hipGraphs instead of launching the chain eagerly (default: eager — the host enqueues an
                                    iteration faster than the GPU retires it, and plain launches are RCCL's best-trodden path) */
-#define DOPF_F_COMM_P2P    1024  /* dopf_multi_*: the consensus sum by the peer exchange (dopf_xchg_* below) instead of RCCL */
+#define DOPF_F_COMM_P2P    1024  /* dopf_multi_*: the consensus sum by the peer exchange (dopf_xchg_* below) instead of RCCL.
+                                   (Rehearsals that put several shards on ONE device: every shard's stream then needs a hardware
+                                   queue of its own — GPU_MAX_HW_QUEUES — or a waiting exchange kernel sits in front of the peer
+                                   it waits for and the wait times out. One shard per device cannot run into that.)        */
 #define DOPF_F_DEBUG_LEAVE  2048  /* tests: the active-set storage body declares every third storage uncertified, so that the
                                    hand-over to the scan body is exercised in every kernel variant                        */
 #define DOPF_F_DEBUG_ROOT_CAP 128 /* tests: the scan kernel's root search gives up after 2 iterations instead of

@@ -1,0 +1,95 @@
+"""Started by tests/test_gpu_multi.py (GPU_MAX_HW_QUEUES=8, nothing else alive in the process): the peer exchange of
+dopf_multi_* with several shards on ONE device. See the test's docstring."""
+import gc
+import os
+import sys
+
+import numpy as np
+import torch  # noqa: F401
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import dopf_pkg  # noqa: E402
+
+dopf_pkg.load()
+from decentralopf_jl_amd import _capi, network, synth  # noqa: E402
+from helpers import make_engine, state_of  # noqa: E402
+
+hip = _capi.hip_api()
+CASES = {
+    "network": dict(n_gen=300, n_sto=40, T=24, N=3, L=3, seed=4, fmax_factor=0.8, fmax_min=5),
+    "copper plate": dict(n_gen=3000, n_sto=400, T=24, seed=4),
+    "copper plate T96": dict(n_gen=700, n_sto=90, T=96, seed=5),
+}
+KEYS = ("lam", "mu", "rho", "inj", "avg_U", "avg_K", "flow", "cost")
+
+
+def compare(pp, n, steps, kw, tol):
+    ref = make_engine(hip, pp, **kw)
+    wants = []
+    for k in steps:
+        ref.iterate(k)
+        wants.append(state_of(ref))
+    ref.close()
+    gc.collect()
+    m = _capi.MultiEngine(hip, n, params=_capi.default_params(flags=_capi.F_COMM_P2P, **kw), devices=[0] * n, **pp.engine_kwargs())
+    assert m.shard(0).comm_info()[0] == n
+    for k, want in zip(steps, wants):
+        assert m.iterate(k) == (k, False)
+        for a, b in zip(m.get_primal(), (want["P"], want["D"], want["C"], want["E"])):
+            assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+        first = state_of(m.shard(0))
+        for i in range(n):
+            got = state_of(m.shard(i))
+            for key in KEYS:
+                if want[key].size:
+                    assert np.abs(got[key] - want[key]).max() <= tol * max(1.0, np.abs(want[key]).max()), (key, i, k)
+                    assert np.array_equal(got[key], first[key]), (key, i)        # rank-order sums: bitwise the same
+    m.close()
+    gc.collect()
+
+
+for name, case in CASES.items():
+    kw = dict(case)
+    pp = synth.synthetic_case(kw.pop("n_gen"), kw.pop("n_sto"), kw.pop("T"), **kw)
+    # (the literal flow weight makes the network case a 2-cycle that amplifies rounding: few iterations)
+    g = 0.01 if name == "network" else 1.0 / (pp.G + pp.S)
+    for n in (2, 3):
+        compare(pp, n, (1, 4, 7) if name == "network" else (1, 7, 30), dict(eps=0.0, gamma=g), 1e-9)
+        print("equal", name, n, flush=True)
+
+# a consensus vector of several chunks (30 nodes, 50 lines, 24 steps: 3 121 doubles), three shards
+pp = synth.synthetic_case(240, 30, 24, N=30, L=50, seed=41, fmax_factor=0.7, fmax_min=5)
+A = pp.G + pp.S
+assert pp.N * pp.T + 2 * pp.L * pp.T + 1 > 2048
+compare(pp, 3, (1, 5, 21), dict(eps=0.0, gamma=1.0 / A, w_flow=0.3 / A), 1e-8)
+print("chunks ok", flush=True)
+
+# the reference's shipped case: stops like check_convergence! on both shards
+nodes, lines, gens, stos = network.three_node_case()
+pp3 = network.pack(nodes, gens, stos, lines)
+m = _capi.MultiEngine(hip, 2, params=_capi.default_params(flags=_capi.F_COMM_P2P), devices=[0, 0], **pp3.engine_kwargs())
+done, conv = m.iterate(2000)
+assert conv and done == 476 and m.shard(1).get_residuals()[3] == 476
+assert m.iterate(5) == (0, True)
+assert abs(m.shard(0).get_consensus()[4] - 14034.5056) < 1e-3
+m.close()
+gc.collect()
+print("stop ok", flush=True)
+
+# a rank whose peer never sends must not hang: the wait is bounded (wall clock), the kernel ends, the call returns an error
+os.environ["DOPF_XCHG_TIMEOUT_MS"] = "300"
+kw = dict(CASES["copper plate"])
+pp = synth.synthetic_case(kw.pop("n_gen"), kw.pop("n_sto"), kw.pop("T"), **kw)
+m = _capi.MultiEngine(hip, 2, params=_capi.default_params(eps=0.0, gamma=1e-3, flags=_capi.F_COMM_P2P), devices=[0, 0], **pp.engine_kwargs())
+lonely = m.shard(1)
+for n_it in (3, 40):                     # sticky, and later exchanges do not wait again
+    try:
+        lonely.iterate(n_it)
+        raise SystemExit("a lonely shard iterated without its peer")
+    except _capi.DopfError as e:
+        assert "did not arrive" in str(e), e
+m.close()
+print("missing peer ok", flush=True)
+print("p2p worker: ok")
