@@ -46,7 +46,7 @@ class DopfTiming(C.Structure):
     _fields_ = [("tables_ms", C.c_double), ("gen_ms", C.c_double), ("sto_ms", C.c_double),
                 ("slack_ms", C.c_double), ("reduce_ms", C.c_double), ("dual_ms", C.c_double),
                 ("iter_ms", C.c_double), ("empty_ms", C.c_double), ("iters", C.c_int32),
-                ("agents_fused", C.c_int32)]
+                ("agents_fused", C.c_int32), ("tail_fused", C.c_int32)]
 
 
 class DopfCentralResult(C.Structure):
@@ -58,6 +58,7 @@ F_NO_GRAPH = 1
 F_OVERLAP_AGENTS = 2
 F_NO_WARM_START = 4
 F_NO_ROW_SKIP = 8
+F_NO_TAIL_FUSE = 4096
 F_NO_FUSE = 16
 F_COMM_HOST = 64
 F_DEBUG_ROOT_CAP = 128
@@ -159,12 +160,45 @@ class CApi:
 
 
 _hip_api: Optional[CApi] = None
+_runtime_pinned = False
+
+
+def _pin_hip_runtime():
+    """One HIP runtime per process. PyTorch's wheels bundle their own libamdhip64.so / libhsa-runtime64.so (same SONAMEs as
+    the system ROCm's, requested under another file name), so a process that loads libdopf_hip.so first (system runtime) and
+    imports torch later ends up with TWO runtimes: the second one finds no GPU ("No HIP GPUs are available"), and a system
+    RCCL bound to the other copy's runtime is an ABI mismatch. When PyTorch is installed but not imported yet, its copy of the
+    runtime is loaded here first: libdopf_hip.so's DT_NEEDED libamdhip64.so.7 then binds to it by SONAME, and a later
+    `import torch` finds its runtime already in place. Without PyTorch (a C or Julia host) nothing happens: system ROCm."""
+    global _runtime_pinned
+    if _runtime_pinned:
+        return
+    _runtime_pinned = True
+    import sys
+    if "torch" in sys.modules:
+        return                          # its runtime is loaded already; ours will bind to it
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return                  # (an unusable bundle: leave everything to the system runtime)
 
 
 def hip_api() -> CApi:
     """The product library. Raises (never falls back) if it is not built or cannot load."""
     global _hip_api
     if _hip_api is None:
+        _pin_hip_runtime()
         _hip_api = CApi(HIP_LIB_PATH, "dopf_")
     return _hip_api
 

@@ -42,6 +42,13 @@ int fail(dopf_ctx *c, int code, const char *fmt, ...)
     return code;
 }
 
+// a call that owns a temporary context (dopf_central_solve) hands the context's message to dopf_last_error(NULL)
+// before the context goes away
+void keep_error(const dopf_ctx *c)
+{
+    if (c && c->err[0]) { strncpy(g_create_err, c->err, 511); g_create_err[511] = 0; }
+}
+
 }  // namespace dopf
 
 namespace {
@@ -113,10 +120,17 @@ static bool slice_dual(const DevView &v, bool single)
     return single && std::max(NT, LT) <= kSmallConsensus && NT <= 256;     // k_dual_price_small: 8 chunks of 32 entries
 }
 
+// the whole tail of the iteration rides in the x-update launch (k_agents / k_sto / the generator kernel): true single-GPU chain only
+static bool tail_fused(const dopf_ctx *c, bool single)
+{
+    return single && c->comm == nullptr && c->v.tailDev != nullptr;
+}
+
 void enqueue_local(dopf_ctx *c, bool single)
 {
     DevView v = c->v;
     v.sliceDual = slice_dual(v, single) ? 1 : 0;
+    v.tail = tail_fused(c, single) ? v.tailDev : nullptr;
     launch_tables(v, c->main);
     const bool fork = v.nGenItems > 0 && v.nStoItems > 0 && (c->q.flags & DOPF_F_OVERLAP_AGENTS);
     if (v.fuseAgents) {
@@ -132,12 +146,14 @@ void enqueue_local(dopf_ctx *c, bool single)
         launch_gen_update(v, c->main);
         launch_sto_update(v, c->lc, c->main);
     }
+    if (v.tail) return;                    // sums, dual step and stop test happened in the launch above
     launch_slack(v, c->main);
     launch_reduce(v, c->main);
 }
 
 void enqueue_apply(dopf_ctx *c, bool single, const XchgView *xd)
 {
+    if (tail_fused(c, single)) return;
     DevView v = c->v;
     v.sliceDual = slice_dual(v, single) ? 1 : 0;
     launch_dual(v, c->main, xd);
@@ -198,6 +214,8 @@ int build_graph(dopf_ctx *c, int iters, hipGraphExec_t *out)
 // a storage sub-problem that hit the root search's iteration cap leaves an unconverged row behind: report it
 int check_solver(dopf_ctx *c)
 {
+    if (c->host_st.tail_timeout)
+        return fail(c, DOPF_E_DEVICE, "the block sums of an iteration did not arrive in the launch's tail block in time; the state is not valid");
     if (c->host_st.xchg_timeout)
         return fail(c, DOPF_E_DEVICE, "peer exchange: a rank's part of the consensus sum did not arrive in time; the state is not valid");
     if (c->host_st.solver_fail > c->solver_fail_seen) {
@@ -320,6 +338,26 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     for (int i = 0; i < G; ++i) if (!(gpm[i] >= 0)) { fail(c, DOPF_E_INVALID, "negative generator capacity"); return bail(DOPF_E_INVALID); }
     for (int i = 0; i < S; ++i) if (!(spm[i] >= 0) || !(sem[i] >= 0)) { fail(c, DOPF_E_INVALID, "negative storage capacity"); return bail(DOPF_E_INVALID); }
 
+    TailView tvh{};
+    bool tail_ok = false;
+    {
+        // One-launch iterations (kernels_agents.hip, "the tail of the iteration inside the x-update launch"): fixed-point scales
+        // from the problem's bounds — |sum of net injections| <= sum of pmax (a storage's D - C lies in [-pmax, pmax]),
+        // |cost| <= T * sum |mc| pmax (storages: 2 pmax) — so that no accumulator can overflow
+        // (64 bits = sign + 53 value bits + the 10-bit arrival count).
+        long double bi = 1.0L, bc = 1.0L;
+        for (int i = 0; i < G; ++i) { bi += gpm[i]; bc += (long double)T * std::fabs(gmc[i]) * gpm[i]; }
+        for (int i = 0; i < S; ++i) { bi += spm[i]; bc += (long double)T * std::fabs(smc[i]) * 2.0 * spm[i]; }
+        const bool fin = std::isfinite((double)bi) && std::isfinite((double)bc);
+        const int ki = fin ? 52 - (int)std::ceil(std::log2((double)bi)) : -1, kc = fin ? 52 - (int)std::ceil(std::log2((double)bc)) : -1;
+        const bool chain = v.genTT2 > 0 && (S == 0 || v.use_warm) && G + S > 0;       // pair kernels / k_agents / k_sto
+        tail_ok = (N == 1 && L == 0 && chain && ki >= 8 && kc >= 0 &&
+                    !(q->flags & (DOPF_F_NO_TAIL_FUSE | DOPF_F_OVERLAP_AGENTS)) &&       // (two streams: the storage launch does not follow the generators')
+                    !getenv("DOPF_NO_TAIL_FUSE")) ? 1 : 0;
+        tvh.accStride = (T + 1 + 15) / 16 * 16;                   // replicas on 128-byte lines of their own
+        tvh.scaleInj = std::ldexp(1.0, std::max(0, std::min(ki, 60))); tvh.invInj = 1.0 / tvh.scaleInj;
+        tvh.scaleCost = std::ldexp(1.0, std::max(0, std::min(kc, 60))); tvh.invCost = 1.0 / tvh.scaleCost;
+    }
     std::vector<Item> gitems, sitems;
     std::vector<int> ngb, nsb, ngib, nsib;
     {
@@ -353,7 +391,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     if (v.fuseAgents && v.genChunk > 0 && !v.genSkip && v.genChunk <= kGenStreamRows * v.genR2 && !getenv("DOPF_NO_GEN_STREAM")) {
         // as many generator blocks as find a wave slot next to the storage blocks (3 blocks of 256 per CU at the fused
         // kernel's register count): all resident from the start; at least a quarter of the chip
-        int nb = 3 * 256 - v.nStoItems;
+        int nb = 3 * 256 - v.nStoItems - (tail_ok ? 1 : 0);        // (tail in the launch: one slot for the tail block)
         if (const char *e = getenv("DOPF_GEN_BLOCKS")) nb = atoi(e);          // (experiments)
         v.genBlocks = std::min(v.nGenItems, std::max(nb, 192));
     }
@@ -429,6 +467,15 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     TRY(dev_alloc(c, &v.part2, (size_t)N * v.reduceRB * T)); TRY(dev_alloc(c, &v.part2_cost, v.reduceRB));
     TRY(dev_alloc(c, &v.reduce_ticket, (size_t)N * ((T + 31) / 32)));
     TRY(dev_alloc(c, &v.dual_ticket, 1));
+    if ((v.nGenItems + v.nStoItems) / kAccRep + 2 > 1000) tail_ok = false;   // (the 10-bit arrival count of a replica slot)
+    if (tail_ok) {
+        TRY(dev_alloc(c, &tvh.acc, (size_t)2 * kAccRep * tvh.accStride));
+        tvh.expect = (v.fuseAgents && v.genBlocks > 0 && !v.genSkip ? v.genBlocks : v.nGenItems) + v.nStoItems;
+        TailView *tvd = nullptr;
+        TRY(dev_alloc(c, &tvd, 1, false));
+        HIPTRY(hipMemcpy(tvd, &tvh, sizeof tvh, hipMemcpyHostToDevice));
+        v.tailDev = tvd;
+    }
     v.splitDual = getenv("DOPF_SPLIT_DUAL") ? 1 : 0;
     double *cons = nullptr;
     TRY(dev_alloc(c, &cons, NT + 2 * LT + 1));
@@ -525,9 +572,16 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
     if (!c || !out || n_iters < 1 || n_iters > 4096) return fail(c, DOPF_E_INVALID, "bad argument");
     DeviceGuard guard(c->device);
     DevView v = c->v;
+    if (c->comm) return fail(c, DOPF_E_INVALID, "dopf_iterate_timed drives the single-GPU chain: not on a context joined to a communicator");
     v.sliceDual = slice_dual(v, true) ? 1 : 0;
+    v.tail = tail_fused(c, true) ? v.tailDev : nullptr;
     enum { E_T0, E_T1, E_G0, E_G1, E_S0, E_S1, E_K0, E_K1, E_R1, E_D1, E_X0, E_X1, E_N };
-    std::vector<hipEvent_t> ev((size_t)n_iters * E_N);
+    struct Events {                                     // destroyed on every way out
+        std::vector<hipEvent_t> v;
+        ~Events() { for (auto e : v) if (e) hipEventDestroy(e); }
+    } evs;
+    evs.v.assign((size_t)n_iters * E_N, nullptr);
+    std::vector<hipEvent_t> &ev = evs.v;
     for (auto &e : ev) HIPCHK(c, hipEventCreate(&e));
     const bool fork = v.nGenItems > 0 && v.nStoItems > 0 && (c->q.flags & DOPF_F_OVERLAP_AGENTS);
     for (int i = 0; i < n_iters; ++i) {
@@ -546,11 +600,11 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
         hipEventRecord(e[E_S1], ss);
         if (fork) { hipEventRecord(c->evJoin, c->side); hipStreamWaitEvent(c->main, c->evJoin, 0); }
         hipEventRecord(e[E_K0], c->main);
-        launch_slack(v, c->main);
+        if (!v.tail) launch_slack(v, c->main);
         hipEventRecord(e[E_K1], c->main);
-        launch_reduce(v, c->main);
+        if (!v.tail) launch_reduce(v, c->main);
         hipEventRecord(e[E_R1], c->main);
-        launch_dual(v, c->main);
+        if (!v.tail) launch_dual(v, c->main);
         hipEventRecord(e[E_D1], c->main);
         hipEventRecord(e[E_X0], c->main);
         hipEventRecord(e[E_X1], c->main);
@@ -577,7 +631,7 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
     out->reduce_ms *= inv; out->dual_ms *= inv; out->iter_ms *= inv; out->empty_ms *= inv;
     out->iters = n_iters;
     out->agents_fused = v.fuseAgents;
-    for (auto &e : ev) hipEventDestroy(e);
+    out->tail_fused = v.tail ? 1 : 0;
     return DOPF_OK;
 }
 

@@ -22,7 +22,10 @@ int calloc_dev(dopf_ctx *c, Tp **out, size_t n)
     const size_t bytes = std::max<size_t>(n, 1) * sizeof(Tp);
     HIPCHK(c, hipMalloc(&p, bytes));
     c->allocs.push_back(p);                 // freed by dopf_destroy
+    // (the context's stream does not synchronise with the null stream: the blocking copies that fill some of these arrays
+    // must not overtake the zeroing — wait for it here)
     HIPCHK(c, hipMemsetAsync(p, 0, bytes, c->main));
+    HIPCHK(c, hipStreamSynchronize(c->main));
     *out = (Tp *)p;
     return DOPF_OK;
 }
@@ -45,7 +48,8 @@ extern "C" int dopf_central_solve(const dopf_problem *p, const dopf_params *q, d
     qq.flags &= ~(DOPF_F_OVERLAP_AGENTS);
     int rc = dopf_create(&c, p, &qq);       // sorted agents, items, node maps, partial-sum arrays, P/D/C/E (zero)
     if (rc) return rc;
-    struct Guard { dopf_ctx *c; ~Guard() { dopf_destroy(c); } } guard{c};
+    // (callers read dopf_last_error(NULL): the temporary context's message has to outlive it)
+    struct Guard { dopf_ctx *c; ~Guard() { keep_error(c); dopf_destroy(c); } } guard{c};
     DeviceGuard dev(c->device);
     const DevView &v = c->v;
     const int N = v.N, L = v.L, T = v.T, G = v.G, S = v.S;

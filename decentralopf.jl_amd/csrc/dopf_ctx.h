@@ -30,6 +30,7 @@ struct dopf_ctx {
 namespace dopf {
 
 int fail(dopf_ctx *c, int code, const char *fmt, ...);
+void keep_error(const dopf_ctx *c);          // the context's message becomes what dopf_last_error(NULL) returns
 void enqueue_local(dopf_ctx *c, bool single);
 void enqueue_apply(dopf_ctx *c, bool single, const XchgView *xd = nullptr);
 void drop_graphs(dopf_ctx *c);

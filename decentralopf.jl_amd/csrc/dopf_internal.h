@@ -40,6 +40,16 @@ struct Status {
     double res[3];          // lambda / mu / rho residual inf-norms of the last checked iteration
     double total_cost;
     int xchg_timeout;       // peer exchange: a peer's part of the consensus sum did not arrive in time (sticky)
+    int tail_timeout;       // tail in the launch: the block sums of an iteration did not all arrive in time (sticky)
+    int tail_par;           // tail in the launch: which of the two accumulator sets the next launch adds into
+};
+
+// accumulators of the one-launch iterations (kernels_agents.hip); lives in device memory
+struct TailView {
+    long long *acc;                 // [2 sets][kAccRep][accStride]: slots 0..T-1 injection sums, slot T cost
+    int accStride;
+    int expect;                     // blocks that add to every slot (generator blocks + storage items)
+    double scaleInj, invInj, scaleCost, invCost;        // fixed-point scales (powers of two) and their inverses
 };
 
 struct DevView {
@@ -101,10 +111,21 @@ struct DevView {
     int *walk_flag, *walk_any;                      // [l + L*t], [t]: the slack sums of (l,t) need the per-node cases (set by the dual step)
     double *part2, *part2_cost;                     // [(n*RB + rb)*T + t], [rb]
     int *dual_ticket;                               // [1] blocks of the one-launch dual/price kernel that have finished
+    // One-launch iterations (one node, no lines, single-GPU chain; kernels_agents.hip "the tail of the iteration inside the
+    // x-update launch"): every block of the x-update adds its per-timestep injection sums and its cost into integer
+    // accumulators (fixed point + arrival count in one 64-bit atomic add), and one extra block of the launch waits for the
+    // counts and runs the whole tail of the iteration. No k_reduce, no dual kernel, one kernel boundary per iteration.
+    const TailView *tail;                           // per launch: non-null = this launch chain works that way
+    const TailView *tailDev;                        // the context's TailView in device memory (null: not supported for this problem)
     int *reduce_ticket;                             // [n]
     double *cons;
     Status *st;
 };
+
+#ifndef DOPF_ACC_REP
+#define DOPF_ACC_REP 16
+#endif
+constexpr int kAccRep = DOPF_ACC_REP;     // replicas of the accumulators (a block adds into replica blockIdx % kAccRep: 1/16 of the adds per address)
 
 // consensus states up to this many (n,t) / (l,t) entries take the one-block dual step
 constexpr size_t kSmallConsensus = 4096;
@@ -112,6 +133,36 @@ constexpr size_t kSmallConsensus = 4096;
 #define DOPF_STREAM_ROWS 6
 #endif
 constexpr int kGenStreamRows = DOPF_STREAM_ROWS;          // rows per lane and item in the streaming generator blocks (one batch of loads)
+
+// check_convergence!, convergence.jl:1-31 (one thread). The status words a stop test starts from are loaded early by
+// callers that can (a load at the very end of a one-block kernel is a round trip on its critical path).
+struct StatusPre { int iteration, converged, iters_total; };
+__device__ __forceinline__ StatusPre status_load(const DevView &v)
+{
+    StatusPre s;
+    s.iteration = v.st->iteration; s.converged = v.st->converged; s.iters_total = v.st->iters_total;
+    return s;
+}
+
+__device__ __forceinline__ void status_update(const DevView &v, const StatusPre s, double r0, double r1, double r2)
+{
+    Status *st = v.st;
+    int conv = s.converged, it = s.iteration;
+    if (it != 1) {                                                        // convergence.jl:3
+        st->res[0] = r0; st->res[1] = r1; st->res[2] = r2;
+        conv = (r0 < v.eps) && (r1 < v.eps) && (r2 < v.eps);
+        st->converged = conv;
+    }
+    st->iters_total = s.iters_total + 1;
+    if (!conv) it += 1;                                                   // convergence.jl:25-30
+    st->iteration = it;
+    st->halt = conv || (v.max_iters > 0 && it > v.max_iters);
+}
+
+__device__ __forceinline__ void status_update(const DevView &v, double r0, double r1, double r2)
+{
+    status_update(v, status_load(v), r0, r1, r2);
+}
 
 struct Launch {
     int stoLPS, stoNCH;

@@ -24,6 +24,11 @@ namespace dopf {
 #if defined(DOPF_STATS) || defined(DOPF_BLOCK_STAMPS)
 __device__ unsigned long long g_timeline[8192 * 8 + 8192 * 8];      // per wave of the storage body: wall-clock stamps (100 MHz)
 #endif
+#ifdef DOPF_BLOCK_STAMPS
+#define DOPF_TAIL_STAMP(i) { if (threadIdx.x == 0) g_timeline[(i)] = wall_clock64(); }
+#else
+#define DOPF_TAIL_STAMP(i)
+#endif
 #ifdef DOPF_STATS
 #define DOPF_STAMP(i) { if (lane == 0 && rep == 0 && round == 0) { const int w_ = blk * 4 + (tid >> 6); if (w_ < 8192) g_timeline[w_ * 8 + (i)] = wall_clock64(); } }
 #else
@@ -42,6 +47,139 @@ __device__ __forceinline__ double rcp64(double x)
     r = fma(fma(-x, r, 1.0), r, r);
     r = fma(fma(-x, r, 1.0), r, r);
     return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the tail of the iteration inside the x-update launch (DevView::tailFused; one node, no lines, single-GPU chain)
+// ------------------------------------------------------------------------------------------------
+//
+// Replaces, for that case, the agent loop of Result(...) (reference src/structures/results.jl:72-106), update_duals!
+// (src/optimization/update_duals.jl:1-39) and check_convergence! (src/optimization/convergence.jl:1-31) as two more
+// launches (k_reduce, k_dual_price_small) by one extra block of the launch itself:
+//   * every block ADDS its per-timestep sums of net injection and its cost into replica blockIdx % kAccRep of a set of
+//     64-bit integer accumulators with ONE device-scope atomic add per value, fire and forget (the block does not wait for
+//     them and exits). The addend is (round(x * 2^k) << kAccCntBits) + 1: the upper 54 bits carry the value in fixed point
+//     (k from the problem's bounds, so that no sum can overflow; integer addition commutes, so the totals do not depend on
+//     the order in which blocks finish: bitwise reproducible), the low 10 bits count the contributions that have landed;
+//   * the launch's LAST block (dispatched after all others, so every block it waits for is running or done: no deadlock
+//     whatever the residency) polls the accumulators; thread t owns slot t and is done when the counts of its slot over
+//     the replicas add up to the number of contributing blocks — the data is its own arrival signal, one memory round
+//     trip between the last block's adds and the tail, no ticket, no fence: value and count arrive in the same atomic;
+//   * it then runs the tail of the iteration — injection, imbalance, lambda step, price, residual, stop test: the
+//     arithmetic of k_dual_price_small's copper-plate path — and zeroes the accumulators for the next launch.
+// The wait is bounded by wall clock (Status::tail_timeout, DOPF_E_DEVICE): the kernel always ends.
+// (First version: every block waited for its adds, took a two-level ticket, the last one drained the accumulators with
+// atomic exchanges — four dependent device-scope round trips of ~2.5 us each next to the streaming blocks: as slow as the
+// two launches it replaced.)
+#ifdef DOPF_TAIL_NOINLINE
+#define DOPF_TAIL_INLINE __attribute__((noinline))
+#else
+#define DOPF_TAIL_INLINE __forceinline__
+#endif
+constexpr int kAccCntBits = 10;
+constexpr unsigned long long kAccCntMask = (1ull << kAccCntBits) - 1ull;
+
+// (every block of a launch reads the parity word once: it changes only at the very end of a launch, in the tail block)
+// (the accumulators' description lives in device memory, DevView::tail points at it: one pointer in the kernel arguments
+// instead of seven more live scalars in kernels that spill scalars already)
+template <bool COUNTED = true>
+__device__ __forceinline__ void acc_add(const TailView &tv, int par, int slot, double x, double scale)
+{
+    const long long q = __double2ll_rn(x * scale);
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(tv.acc) +
+                            ((size_t)par * kAccRep + (size_t)(blockIdx.x % kAccRep)) * tv.accStride + slot;
+    __hip_atomic_fetch_add(p, ((unsigned long long)q << kAccCntBits) + (COUNTED ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The tail block (inlined into the kernels that can carry it: it must stay below their register budgets — a lane pair owns
+// a slot, each lane polls half of the replicas, 8 loads in flight). Two sets of accumulators take turns (Status::tail_par):
+// the set an iteration used is zeroed by the NEXT tail block while it waits, not between the last arrival and the dual step.
+// (`self`: the context's view in DEVICE memory — what this block needs is read there, inside its branch, instead of
+// widening the set of kernel arguments every block of the launch loads at its start)
+__device__ DOPF_TAIL_INLINE void tail_block(const DevView *self)
+{
+    const DevView &v = *self;
+    const TailView tv = *v.tailDev;
+    const int expect = tv.expect;
+    __shared__ double wmaxT[8];
+    __shared__ int badT;
+    const int tid = threadIdx.x, T = v.T, nth = (int)blockDim.x;       // 256 or 512 threads
+    constexpr int HR = kAccRep / 2;
+    DOPF_TAIL_STAMP(0)
+    if (v.st->halt) return;
+    const int par = v.st->tail_par;
+    StatusPre spre{};
+    if (tid == 0) { spre = status_load(v); badT = 0; }
+    {   // the other set: read by the previous launch's tail, not touched by this launch
+        unsigned long long *z = reinterpret_cast<unsigned long long *>(tv.acc) + (size_t)(par ^ 1) * kAccRep * tv.accStride;
+        for (int i = tid; i < kAccRep * tv.accStride; i += nth) __hip_atomic_store(z + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const unsigned long long limit = 200000000ull;                      // 2 s of the 100 MHz wall clock
+    const unsigned long long tstart = wall_clock64();
+    __syncthreads();
+    DOPF_TAIL_STAMP(1)
+    double rl = 0.0;
+    const int half = tid & 1;
+    for (int t0 = 0; t0 <= T; t0 += nth / 2) {          // slot T = cost
+        const int t = t0 + (tid >> 1);
+        const bool act = t <= T;                        // (whole lane pairs)
+        const int tc = t < T ? t : 0;
+        const double dem = v.demand[tc], lam_old = v.lam[tc], s_old = v.s[tc];
+        const unsigned long long *base = reinterpret_cast<const unsigned long long *>(tv.acc) +
+                                         ((size_t)par * kAccRep + (size_t)half * HR) * tv.accStride + (act ? t : 0);
+        long long isum = 0;
+        bool ok = !act;
+        for (unsigned round = 1; __any(!ok); ++round) {          // (every lane stays: the pair sums are wave shuffles)
+            unsigned long long x[HR];
+#pragma unroll
+            for (int r = 0; r < HR; ++r)
+                x[r] = __hip_atomic_load(base + (size_t)r * tv.accStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned cnt = 0;
+            long long sum = 0;
+#pragma unroll
+            for (int r = 0; r < HR; ++r) {
+                cnt += (unsigned)(x[r] & kAccCntMask);
+                sum += (long long)(x[r] & ~kAccCntMask) >> kAccCntBits;       // (arithmetic shift: the value part is signed)
+            }
+            cnt += __shfl_xor(cnt, 1);
+            sum += __shfl_xor(sum, 1);
+            if (!ok && (int)cnt == expect) { ok = true; isum = sum; }
+            // (the clock is a scalar memory read of its own: not in every round; a round is one memory round trip)
+            if ((round & 255u) == 0u && wall_clock64() - tstart > limit) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) { badT = 1; continue; }
+        DOPF_TAIL_STAMP(2)
+        if (!act || half) continue;
+        if (t < T) {
+            const double tot = (double)isum * tv.invInj;
+            const double xi = tot - dem;                          // results.jl:58-100 (one node: imbalance = its injection)
+            v.cons[t] = tot;
+            v.inj[t] = xi;
+            v.s_used[t] = s_old;
+            v.s[t] = xi;
+            const double ln = lam_old + v.gamma * xi;             // update_duals.jl:8-13
+            v.lam_used[t] = lam_old;
+            v.lam[t] = ln;
+            v.price[t] = ln;                                      // no lines: the nodal price is lambda
+            rl = fmax(rl, fabs(ln - lam_old));
+        } else {
+            const double ctot = (double)isum * tv.invCost;
+            v.cons[T] = ctot;
+            v.st->total_cost = ctot;
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) rl = fmax(rl, __shfl_xor(rl, d));
+    if ((tid & 63) == 0) wmaxT[tid >> 6] = rl;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (only LDS data crosses: the stores above need not be acknowledged first)
+    DOPF_TAIL_STAMP(3)
+    if (tid == 0) {
+        if (badT) { v.st->tail_timeout = 1; v.st->halt = 1; return; }           // (sticky; the host reports DOPF_E_DEVICE)
+        double r0 = 0.0;
+        for (int q = 0; q < nth / 64; ++q) r0 = fmax(r0, wmaxT[q]);
+        v.st->tail_par = par ^ 1;
+        status_update(v, spre, r0, 0.0, 0.0);
+    }
 }
 
 // box2 coefficients of a step whose Psi is linear with slope kap around the solution: a = w + kap, b = kap,
@@ -164,11 +302,14 @@ __global__ __launch_bounds__(512) void k_gen_update(DevView v)
 // LDS_ONLY: the barrier waits for this wave's LDS traffic only. __syncthreads() also drains every global load in
 // flight (s_waitcnt vmcnt(0)) — in the streaming blocks those are the NEXT item's rows, i.e. exactly the overlap the
 // streaming is for. Only LDS data crosses this barrier.
-template <int BS, bool LDS_ONLY = false>
+template <int BS, bool TAIL, bool LDS_ONLY = false>
 __device__ __forceinline__ void gen_pair_sums(const DevView &v, const int blk, const int tid, const int r, const int tt,
                                               double acc0, double acc1, double cost, double (*red)[BS], double *wc)
 {
     const int T = v.T, TT = v.genTT2, R = v.genR2;
+    TailView tv{};                                           // TAIL: the launch chain carries the iteration's tail
+    int par = 0;
+    if (TAIL) { tv = *v.tail; par = v.st->tail_par; }        // (uniform scalar loads, in flight with the LDS traffic below)
     for (int d = 32; d > 0; d >>= 1) cost += __shfl_xor(cost, d);
     red[0][tid] = acc0; red[1][tid] = acc1;
     if ((tid & 63) == 0) wc[tid >> 6] = cost;
@@ -177,20 +318,27 @@ __device__ __forceinline__ void gen_pair_sums(const DevView &v, const int blk, c
     if (r == 0 && tt < TT) {
         double s0 = 0.0, s1 = 0.0;
         for (int q = 0; q < R; ++q) { s0 += red[0][q * TT + tt]; s1 += red[1][q * TT + tt]; }
-        v.part_ginj[(size_t)blk * T + 2 * tt] = s0;
-        v.part_ginj[(size_t)blk * T + 2 * tt + 1] = s1;
+        if (TAIL) {
+            acc_add(tv, par, 2 * tt, s0, tv.scaleInj);
+            acc_add(tv, par, 2 * tt + 1, s1, tv.scaleInj);
+        } else {
+            v.part_ginj[(size_t)blk * T + 2 * tt] = s0;
+            v.part_ginj[(size_t)blk * T + 2 * tt + 1] = s1;
+        }
     }
     if (tid == 0) {
         double c = 0.0;
         for (int q = 0; q < BS / 64; ++q) c += wc[q];
-        v.part_gcost[blk] = c;
+        if (TAIL) acc_add(tv, par, T, c, tv.scaleCost);
+        else v.part_gcost[blk] = c;
     }
 }
 
 // Copper plate, even T: each thread owns TWO consecutive timesteps of an agent, so every P access is a
 // 16-byte-per-lane double2 (the widest coalesced form), half as many load/store instructions per byte.
-template <int BS, bool CHECK_HALT = false>
-__device__ __forceinline__ void gen_pair_body(const DevView &v, const int blk)
+// returns false when the block found the halted state (nothing stored, nothing added)
+template <int BS, bool TAIL, bool CHECK_HALT = false>
+__device__ __forceinline__ bool gen_pair_body(const DevView &v, const int blk)
 {
     const int halt = CHECK_HALT ? v.st->halt : 0;        // (the load is in flight with the ones below)
     __shared__ double red[2][BS];
@@ -240,8 +388,9 @@ __device__ __forceinline__ void gen_pair_body(const DevView &v, const int blk)
             }
         }
     }
-    if (CHECK_HALT && halt) return;
-    gen_pair_sums<BS>(v, blk, tid, r, tt, acc0, acc1, cost, red, wc);
+    if (CHECK_HALT && halt) return false;
+    gen_pair_sums<BS, TAIL>(v, blk, tid, r, tt, acc0, acc1, cost, red, wc);
+    return true;
 }
 
 // Generator blocks of the fused launch (one node, items = equal cuts of <= GU rows per lane): a block STAYS and walks the
@@ -254,8 +403,9 @@ __device__ __forceinline__ void gen_pair_body(const DevView &v, const int blk)
 // its sums run over ALL its items in registers and meet once, at the block's end (one partial row per BLOCK: fixed
 // order, bitwise reproducible; no LDS traffic or barrier inside the loop). (Tried: items drawn from a counter so that blocks starting late can help
 // — a same-address device-scope atomic per item costs more than it balances on eight L2s: 26 vs 21 us.)
-template <int BS>
-__device__ __forceinline__ void gen_pair_stream(const DevView &v, const int first, const int stride)
+// returns false when the block found the halted state (nothing stored, nothing added)
+template <int BS, bool TAIL>
+__device__ __forceinline__ bool gen_pair_stream(const DevView &v, const int first, const int stride)
 {
     constexpr int GU = kGenStreamRows;
     __shared__ double red[2][BS];
@@ -269,7 +419,7 @@ __device__ __forceinline__ void gen_pair_stream(const DevView &v, const int firs
     const int t2c = 2 * tt;                                  // one node: its price is entry 0 of every timestep
     const double sh0 = fma(gam, v.s[t2c], v.price[(size_t)N * t2c]) * inv;
     const double sh1 = fma(gam, v.s[t2c + 1], v.price[(size_t)N * (t2c + 1)]) * inv;
-    if (first >= nI) return;
+    if (first >= nI) return halt == 0;
     double2 *P2 = reinterpret_cast<double2 *>(v.P);
     const size_t half = (size_t)(T >> 1);
     double2 pa[GU], pb[GU];
@@ -311,7 +461,7 @@ __device__ __forceinline__ void gen_pair_stream(const DevView &v, const int firs
     for (;;) {
         const int j = i + stride;
         DOPF_GEN_LOAD(min(j, nI - 1), pb, mcb, pmb)
-        if (halt) return;                                    // (uniform) nothing is stored in a halted state
+        if (halt) return false;                              // (uniform) nothing is stored in a halted state
         DOPF_GEN_WORK(i, pa, mca, pma)
         if (j >= nI) break;
         const int k = j + stride;
@@ -320,15 +470,21 @@ __device__ __forceinline__ void gen_pair_stream(const DevView &v, const int firs
         if (k >= nI) break;
         i = k;
     }
-    gen_pair_sums<BS>(v, first, tid, r, tt, acc0, acc1, cost, red, wc);       // row `first` of the partials = this block
+    gen_pair_sums<BS, TAIL>(v, first, tid, r, tt, acc0, acc1, cost, red, wc);       // row `first` of the partials = this block
 #undef DOPF_GEN_LOAD
 #undef DOPF_GEN_WORK
+    return true;
 }
 
+// MODE 0: partial rows for k_reduce; 1: sums into the accumulators, a later launch of the chain (k_sto) carries the tail block;
+// 2: no storage launch follows, this launch carries the tail block itself. (Instantiations of their own: the tail's registers
+// would cost the common kernel a wave per SIMD, and the chains without a tail keep the code they had.)
+template <int MODE>
 __global__ __launch_bounds__(512) void k_gen_update_pair(DevView v)
 {
+    if (MODE == 2 && (int)blockIdx.x == v.nGenItems) { tail_block(v.self); return; }
     if (v.st->halt) return;
-    gen_pair_body<512>(v, blockIdx.x);
+    gen_pair_body<512, MODE != 0>(v, blockIdx.x);
 }
 
 // Row skipping variant (used when a block sweeps many agents, so that its fixed cost is amortised): in a
@@ -337,7 +493,7 @@ __global__ __launch_bounds__(512) void k_gen_update_pair(DevView v)
 // mc/(w+gamma) + min_t shift_t >= 0, an all-pmax row stays iff mc/(w+gamma) + max_t shift_t <= 0 (the update
 // then clamps every element back onto the same bound), so such a row is neither read nor written — its
 // contribution to the sums is 0 or pmax. Results are identical to the full sweep, bit for bit.
-template <int BS>
+template <int BS, bool TAIL>
 __device__ __forceinline__ void gen_pair_skip_body(const DevView &v, const int blk)
 {
     __shared__ double red[2][BS];
@@ -416,21 +572,30 @@ __device__ __forceinline__ void gen_pair_skip_body(const DevView &v, const int b
         }
         if (tt == 0 && r < R) flg[p & 1][r] = 3;              // free again two passes later
     }
-    gen_pair_sums<BS>(v, blk, tid, r, tt, acc0, acc1, cost, red, wc);
+    gen_pair_sums<BS, TAIL>(v, blk, tid, r, tt, acc0, acc1, cost, red, wc);
 }
 
+template <int MODE>
 __global__ __launch_bounds__(512) void k_gen_update_pair_skip(DevView v)
 {
+    if (MODE == 2 && (int)blockIdx.x == v.nGenItems) { tail_block(v.self); return; }
     if (v.st->halt) return;
-    gen_pair_skip_body<512>(v, blockIdx.x);
+    gen_pair_skip_body<512, MODE != 0>(v, blockIdx.x);
 }
 
 void launch_gen_update(const DevView &v, hipStream_t s)
 {
     if (v.nGenItems == 0) return;
     if (v.L > 0) hipLaunchKernelGGL(k_gen_update<true>, dim3(v.nGenItems), dim3(512), 0, s, v);
-    else if (v.genTT2 > 0 && v.genSkip) hipLaunchKernelGGL(k_gen_update_pair_skip, dim3(v.nGenItems), dim3(512), 0, s, v);
-    else if (v.genTT2 > 0) hipLaunchKernelGGL(k_gen_update_pair, dim3(v.nGenItems), dim3(512), 0, s, v);
+    else if (v.genTT2 > 0 && v.tail && v.nStoItems == 0) {
+        if (v.genSkip) hipLaunchKernelGGL(k_gen_update_pair_skip<2>, dim3(v.nGenItems + 1), dim3(512), 0, s, v);
+        else hipLaunchKernelGGL(k_gen_update_pair<2>, dim3(v.nGenItems + 1), dim3(512), 0, s, v);
+    } else if (v.genTT2 > 0 && v.tail) {
+        if (v.genSkip) hipLaunchKernelGGL(k_gen_update_pair_skip<1>, dim3(v.nGenItems), dim3(512), 0, s, v);
+        else hipLaunchKernelGGL(k_gen_update_pair<1>, dim3(v.nGenItems), dim3(512), 0, s, v);
+    }
+    else if (v.genTT2 > 0 && v.genSkip) hipLaunchKernelGGL(k_gen_update_pair_skip<0>, dim3(v.nGenItems), dim3(512), 0, s, v);
+    else if (v.genTT2 > 0) hipLaunchKernelGGL(k_gen_update_pair<0>, dim3(v.nGenItems), dim3(512), 0, s, v);
     else hipLaunchKernelGGL(k_gen_update<false>, dim3(v.nGenItems), dim3(512), 0, s, v);
 }
 
@@ -656,7 +821,7 @@ struct StoAgent {
 };
 
 // `item_fail`: number of storages of this item the warm start left over (block-uniform); < 0 = read it
-template <int LPS, int NCH, bool LINES>
+template <int LPS, int NCH, bool LINES, bool TAIL = false>
 __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, int item_fail)
 {
     constexpr int NG = 256 / LPS;
@@ -668,6 +833,7 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
     const int T = v.T, N = v.N;
     if (item_fail < 0) item_fail = v.item_fail[blk];
     if (v.use_warm && item_fail == 0) {      // the warm start solved this whole item
+        if (TAIL) return;                    // (nothing to add)
         for (int t = tid; t < T; t += 256) v.part_sinj[(size_t)blk * T + t] = 0.0;
         if (tid == 0) v.part_scost[blk] = 0.0;
         return;
@@ -964,7 +1130,9 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
             if (t < T) {
                 double sum = 0.0;
                 for (int g2 = 0; g2 < NG; ++g2) sum += red[(g2 * LPS + li) * NCH + c];
-                v.part_sinj[(size_t)blk * T + t] = sum;
+                // (tail in the launch: this thread wrote the active-set body's sum of slot t itself, a moment ago)
+                if (TAIL) { const TailView tv = *v.tail; acc_add(tv, v.st->tail_par, t, sum + v.part_sinj_w[(size_t)blk * T + t], tv.scaleInj); }
+                else v.part_sinj[(size_t)blk * T + t] = sum;
             }
         }
     }
@@ -972,7 +1140,10 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
         if (tid < sft) redc[tid] += redc[tid + sft];
         __syncthreads();
     }
-    if (tid == 0) v.part_scost[blk] = redc[0];
+    if (tid == 0) {
+        if (TAIL) { const TailView tv = *v.tail; acc_add(tv, v.st->tail_par, T, redc[0] + v.part_scost_w[blk], tv.scaleCost); }
+        else v.part_scost[blk] = redc[0];
+    }
     if (fails) atomicAdd(&v.st->solver_fail, fails);
 #ifdef DOPF_STATS
     if (st_scans) atomicAdd(&v.st->dbg_scans, st_scans);
@@ -1127,7 +1298,7 @@ __device__ __forceinline__ int next_lane_i(int x)
 }
 
 // returns the number of storages of the item left to the scan (block-uniform)
-template <int LPS, int NCH, bool LINES>
+template <int LPS, int NCH, bool LINES, bool TAIL = false>
 __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, const int halt = 0)
 {
     constexpr int NG = 256 / LPS, TP = LPS * NCH;
@@ -1618,6 +1789,9 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
         for (int d = 32; d > 0; d >>= 1) { cw += __shfl_xor(cw, d); fw += __shfl_xor(fw, d); }
         if (lane == 0) { wcostS[tid >> 6] = cw; wfailS[tid >> 6] = fw; }
     }
+    TailView tv{};                                              // TAIL: the launch carries the iteration's tail
+    int tpar = 0;
+    if (TAIL) { tv = *v.tail; tpar = v.st->tail_par; }          // (uniform scalar loads, in flight across the barrier)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const int blockFail = wfailS[0] + wfailS[1] + wfailS[2] + wfailS[3];     // storages of this item left to the scan kernel
     if (grp == 0) {
@@ -1627,11 +1801,19 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
             if (t < T) {
                 double sum = 0.0;
                 for (int g2 = 0; g2 < NG; ++g2) sum += red[(g2 * LPS + li) * NCH + c];
-                v.part_sinj_w[(size_t)blk * T + t] = sum;
+                // tail in the launch: ONE counted add per block and slot. A block with storages left over for the scan body
+                // parks its sums in its partial row instead; the scan body (same block, same thread per slot) adds both.
+                if (TAIL && blockFail == 0) acc_add(tv, tpar, t, sum, tv.scaleInj);
+                else v.part_sinj_w[(size_t)blk * T + t] = sum;
             }
         }
     }
-    if (tid == 0) { v.part_scost_w[blk] = ((wcostS[0] + wcostS[1]) + wcostS[2]) + wcostS[3]; v.item_fail[blk] = blockFail; }
+    if (tid == 0) {
+        const double cw = ((wcostS[0] + wcostS[1]) + wcostS[2]) + wcostS[3];
+        if (TAIL && blockFail == 0) acc_add(tv, tpar, T, cw, tv.scaleCost);
+        else v.part_scost_w[blk] = cw;
+        v.item_fail[blk] = blockFail;
+    }
     __syncthreads();                                 // (callers rely on the body ending on a barrier)
     { const int rep = 0, round = 0; DOPF_STAMP(6) }
     return blockFail;
@@ -1666,12 +1848,14 @@ __global__ __launch_bounds__(256, DOPF_WARM_WAVES) void k_sto_warm(DevView v)
 
 // Warm start and, in the same block, the cold scan for what it left over: one launch for the storages of the big
 // copper-plate grids (the separate k_sto_update launch mostly found nothing to do).
-template <int LPS, int NCH, bool LINES>
+template <int LPS, int NCH, bool LINES, bool TAIL>
 __global__ __launch_bounds__(256, 3) void k_sto(DevView v)
 {
+    // (TAIL: the generator launch in front of this one has added its sums; the grid's last block is the tail block)
+    if (TAIL && (int)blockIdx.x == v.nStoItems) { tail_block(v.self); return; }
     if (v.st->halt) return;
-    const int left = sto_warm_body<LPS, NCH, LINES>(v, blockIdx.x);         // ends on a __syncthreads: its sto_fail
-    sto_cold_body<LPS, NCH, LINES>(v, blockIdx.x, left);                     // flags are visible to the block here
+    const int left = sto_warm_body<LPS, NCH, LINES, TAIL>(v, blockIdx.x);   // ends on a __syncthreads: its sto_fail
+    sto_cold_body<LPS, NCH, LINES, TAIL>(v, blockIdx.x, left);               // flags are visible to the block here
 }
 
 // All x-updates of one copper-plate iteration in ONE launch: blocks [0, nStoItems) solve storages (warm start,
@@ -1681,24 +1865,26 @@ __global__ __launch_bounds__(256, 3) void k_sto(DevView v)
 // ones (interleaving the two kinds in dispatch order starts the last storage blocks late and costs 50 %).
 // The launch runs at the storage code's 3 waves/SIMD, which starves the streaming generator blocks once the
 // grid is large, so dopf_create only fuses grids whose storage blocks are all resident from the start.
-template <int LPS, int NCH, bool SKIP>
+template <int LPS, int NCH, bool SKIP, bool TAIL>
 __global__ __launch_bounds__(256, 3) void k_agents(DevView v)
 {
     const int nS = v.nStoItems;
 #if defined(DOPF_STATS) || defined(DOPF_BLOCK_STAMPS)
     if (threadIdx.x == 0 && blockIdx.x < 8192 * 4) g_timeline[32768 + 2 * blockIdx.x] = wall_clock64();
 #endif
-    if (!SKIP && (int)blockIdx.x >= nS) {
+    if (TAIL && blockIdx.x == gridDim.x - 1) {
+        tail_block(v.self);
+    } else if (!SKIP && (int)blockIdx.x >= nS) {
         // generator block: its loads do not wait for the halt word
-        if (v.genBlocks > 0) gen_pair_stream<256>(v, blockIdx.x - nS, v.genBlocks);
-        else gen_pair_body<256, true>(v, blockIdx.x - nS);
+        if (v.genBlocks > 0) gen_pair_stream<256, TAIL>(v, blockIdx.x - nS, v.genBlocks);
+        else gen_pair_body<256, TAIL, true>(v, blockIdx.x - nS);
     } else {
         if (v.st->halt) return;
         if ((int)blockIdx.x < nS) {
-            const int left = sto_warm_body<LPS, NCH, false>(v, blockIdx.x);     // ends on a __syncthreads: its sto_fail
-            sto_cold_body<LPS, NCH, false>(v, blockIdx.x, left);                // flags are visible to the block here
+            const int left = sto_warm_body<LPS, NCH, false, TAIL>(v, blockIdx.x);     // ends on a __syncthreads: its sto_fail
+            sto_cold_body<LPS, NCH, false, TAIL>(v, blockIdx.x, left);                // flags are visible to the block here
         } else {
-            gen_pair_skip_body<256>(v, blockIdx.x - nS);
+            gen_pair_skip_body<256, TAIL>(v, blockIdx.x - nS);
         }
     }
 #if defined(DOPF_STATS) || defined(DOPF_BLOCK_STAMPS)
@@ -1733,7 +1919,8 @@ template <int LPS, int NCH>
 static void launch_sto_t(const DevView &v, hipStream_t s)
 {
     if (v.use_warm && v.L == 0) {            // (NCH <= 3 whenever the warm start is on)
-        hipLaunchKernelGGL((k_sto<LPS, (NCH <= 3 ? NCH : 3), false>), dim3(v.nStoItems), dim3(256), 0, s, v);
+        if (v.tail) hipLaunchKernelGGL((k_sto<LPS, (NCH <= 3 ? NCH : 3), false, true>), dim3(v.nStoItems + 1), dim3(256), 0, s, v);
+        else hipLaunchKernelGGL((k_sto<LPS, (NCH <= 3 ? NCH : 3), false, false>), dim3(v.nStoItems), dim3(256), 0, s, v);
         return;
     }
     // with lines the two kernels stay apart: fused, the warm part runs 40 % slower (255 VGPRs, measured)
@@ -1746,9 +1933,14 @@ static void launch_sto_t(const DevView &v, hipStream_t s)
 template <int LPS, int NCH>
 static void launch_agents_t(const DevView &v, hipStream_t s)
 {
-    const dim3 grid(v.nStoItems + (v.genBlocks > 0 && !v.genSkip ? v.genBlocks : v.nGenItems));
-    if (v.genSkip) hipLaunchKernelGGL((k_agents<LPS, NCH, true>), grid, dim3(256), 0, s, v);
-    else hipLaunchKernelGGL((k_agents<LPS, NCH, false>), grid, dim3(256), 0, s, v);
+    const dim3 grid(v.nStoItems + (v.genBlocks > 0 && !v.genSkip ? v.genBlocks : v.nGenItems) + (v.tail ? 1 : 0));
+    if (v.tail) {
+        if (v.genSkip) hipLaunchKernelGGL((k_agents<LPS, NCH, true, true>), grid, dim3(256), 0, s, v);
+        else hipLaunchKernelGGL((k_agents<LPS, NCH, false, true>), grid, dim3(256), 0, s, v);
+    } else {
+        if (v.genSkip) hipLaunchKernelGGL((k_agents<LPS, NCH, true, false>), grid, dim3(256), 0, s, v);
+        else hipLaunchKernelGGL((k_agents<LPS, NCH, false, false>), grid, dim3(256), 0, s, v);
+    }
 }
 
 void launch_agents_fused(const DevView &v, const Launch &lc, hipStream_t s)

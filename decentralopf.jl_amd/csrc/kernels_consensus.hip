@@ -752,37 +752,6 @@ __device__ __forceinline__ void price_body(const DevView &v, size_t i)
     v.price[i] = p;
 }
 
-// check_convergence!, convergence.jl:1-31 (one thread)
-// the status words a stop test starts from: loaded early by callers that can (a load at the very end of a one-block
-// kernel is a round trip on its critical path)
-struct StatusPre { int iteration, converged, iters_total; };
-__device__ __forceinline__ StatusPre status_load(const DevView &v)
-{
-    StatusPre s;
-    s.iteration = v.st->iteration; s.converged = v.st->converged; s.iters_total = v.st->iters_total;
-    return s;
-}
-
-__device__ __forceinline__ void status_update(const DevView &v, const StatusPre s, double r0, double r1, double r2)
-{
-    Status *st = v.st;
-    int conv = s.converged, it = s.iteration;
-    if (it != 1) {                                                        // convergence.jl:3
-        st->res[0] = r0; st->res[1] = r1; st->res[2] = r2;
-        conv = (r0 < v.eps) && (r1 < v.eps) && (r2 < v.eps);
-        st->converged = conv;
-    }
-    st->iters_total = s.iters_total + 1;
-    if (!conv) it += 1;                                                   // convergence.jl:25-30
-    st->iteration = it;
-    st->halt = conv || (v.max_iters > 0 && it > v.max_iters);
-}
-
-__device__ __forceinline__ void status_update(const DevView &v, double r0, double r1, double r2)
-{
-    status_update(v, status_load(v), r0, r1, r2);
-}
-
 template <bool UPDATE>
 __global__ __launch_bounds__(256) void k_dual(DevView v)
 {

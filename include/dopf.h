@@ -115,6 +115,9 @@ typedef struct dopf_params {
                                    (Rehearsals that put several shards on ONE device: every shard's stream then needs a hardware
                                    queue of its own — GPU_MAX_HW_QUEUES — or a waiting exchange kernel sits in front of the peer
                                    it waits for and the wait times out. One shard per device cannot run into that.)        */
+#define DOPF_F_NO_TAIL_FUSE 4096  /* one node, no lines, single-GPU chain: keep the consensus sums and the dual step as launches of
+                                   their own (k_reduce, k_dual_price_small) instead of finishing the iteration inside the
+                                   x-update launch (integer accumulators + the last block's tail) */
 #define DOPF_F_DEBUG_LEAVE  2048  /* tests: the active-set storage body declares every third storage uncertified, so that the
                                    hand-over to the scan body is exercised in every kernel variant                        */
 #define DOPF_F_DEBUG_ROOT_CAP 128 /* tests: the scan kernel's root search gives up after 2 iterations instead of
@@ -199,6 +202,8 @@ typedef struct dopf_timing {
     double empty_ms;    /* an event pair with nothing between: the fixed cost inside every number above */
     int32_t iters;
     int32_t agents_fused;   /* 1: generators and storages ran as one launch */
+    int32_t tail_fused;     /* 1: consensus sums, dual step and stop test ran inside the x-update launch(es): reduce_ms and
+                               dual_ms are empty event pairs */
 } dopf_timing;
 int dopf_iterate_timed(dopf_ctx *ctx, int32_t n_iters, dopf_timing *out);
 

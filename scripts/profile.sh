@@ -13,18 +13,19 @@ ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/prof_$W
 ARGS="bench.py --workload $W --no-cpu-baseline --no-also"      # bench.py defaults: 48 warm-up + 400 timed iterations
 if [ "$MODE" = "driver" ]; then OUT=${OUT}_driver; ARGS="$ARGS --gpus 1 --steps 20 --warmup 5"; fi
-mkdir -p $OUT
+RAW=/tmp/dopf_prof_${W}_$MODE      # raw traces / counter dumps stay on the box (gpurun_out/ is copied back only below 64 MiB)
+rm -rf $RAW; mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp
 cd $ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -- python3 $ARGS > $OUT/trace.json 2> $OUT/trace.err
 if [ "$MODE" != "driver" ]; then
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.json 2> $OUT/fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.json 2> $OUT/write.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $RAW/fetch -- python3 $ARGS > $OUT/fetch.json 2> $OUT/fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $RAW/write -- python3 $ARGS > $OUT/write.json 2> $OUT/write.err
 fi
 python3 - <<PY
 import csv, glob, json, collections
 out = {}
-for f in glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True):
+for f in glob.glob("$RAW/trace/**/*kernel_stats.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
     out["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs") if k in r} for r in rows]
     import shutil; shutil.copy(f, "$OUT/kernel_stats.csv")
@@ -34,7 +35,7 @@ for f in glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True):
 line = json.loads(open("$OUT/trace.json").read().strip().splitlines()[-1])
 W, K, tail = line["warmup"], line["steps"], 32
 gap = max(W + K, 200) - (W + K)
-for f in glob.glob("$OUT/trace/**/*kernel_trace.csv", recursive=True):
+for f in glob.glob("$RAW/trace/**/*kernel_trace.csv", recursive=True):
     rows = sorted((r for r in csv.DictReader(open(f)) if "dopf::" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
     by = collections.defaultdict(list)
     for r in rows:
@@ -54,7 +55,7 @@ for f in glob.glob("$OUT/trace/**/*kernel_trace.csv", recursive=True):
         wr = csv.DictWriter(fh, fieldnames=["Name", "window", "Calls", "AverageNs", "MinNs", "MaxNs"]); wr.writeheader(); wr.writerows(win)
 pmc = {}
 for name in ("fetch", "write"):
-    for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % name, recursive=True):
+    for f in glob.glob("$RAW/%s/**/*counter_collection.csv" % name, recursive=True):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             agg[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))

@@ -171,7 +171,9 @@ def test_hip_is_bitwise_reproducible(hip_api):
     """Fixed-order reductions: two runs give identical bits, with and without the graph."""
     pp = synth.synthetic_case(3000, 300, 24, seed=31)
     # (the fused and the separate launches group their partial sums differently: two families)
-    for family in ((0, 0, _capi.F_NO_GRAPH), (_capi.F_NO_FUSE, _capi.F_NO_FUSE, _capi.F_OVERLAP_AGENTS)):
+    NT = _capi.F_NO_TAIL_FUSE
+    for family in ((0, 0, _capi.F_NO_GRAPH), (_capi.F_NO_FUSE, _capi.F_NO_FUSE, _capi.F_NO_FUSE | _capi.F_NO_GRAPH),
+                   (NT, NT, NT | _capi.F_NO_GRAPH), (NT | _capi.F_NO_FUSE, NT | _capi.F_NO_FUSE, _capi.F_OVERLAP_AGENTS)):
         outs = []
         for flags in family:
             e = make_engine(hip_api, pp, eps=0.0, gamma=1.0 / 3300, flags=flags)
@@ -309,6 +311,50 @@ def test_hip_fused_agents_match_separate_launches(hip_api, case):
         la, lb = a.get_duals()[0], b.get_duals()[0]
         assert np.abs(la - lb).max() <= 1e-10 * (1.0 + np.abs(lb).max())
     assert a.solver_failures() == 0 and b.solver_failures() == 0
+
+
+TAIL = [
+    ("config1 (fused launch, T=24)", lambda: synth.baseline_config(1), 0),
+    ("config2/5 (fused launch, streaming generator blocks, T=96)", lambda: synth.baseline_config(2, scale=0.2), 0),
+    ("config4/5 (generator launch + storage launch, row skipping)", lambda: synth.baseline_config(4, scale=0.2), 0),
+    ("separate launches of a small grid", lambda: synth.synthetic_case(3000, 300, 24, seed=31), _capi.F_NO_FUSE),
+    ("generators only, T=600 (512-thread blocks carry the tail)", lambda: synth.synthetic_case(500, 0, 600, seed=8), 0),
+    ("storages only", lambda: synth.synthetic_case(0, 700, 48, seed=14), 0),
+    ("T=168 (one wave per storage)", lambda: synth.synthetic_case(900, 120, 168, seed=4), 0),
+]
+
+
+@pytest.mark.parametrize("name,make,flags", TAIL, ids=[t[0] for t in TAIL])
+def test_hip_tail_in_the_launch_matches_the_three_launch_chain(hip_api, name, make, flags):
+    """One node, no lines: the iteration's consensus sums, dual step and stop test finished inside the x-update launch
+    (integer accumulators, last block's tail) against k_reduce + k_dual_price_small (DOPF_F_NO_TAIL_FUSE): same iterates
+    up to the rounding of the sums (fixed point vs fp64 in a fixed order), same stopping iteration, and two runs of the
+    one-launch form are bit-identical, graph or eager."""
+    pp = make()
+    g = 1.0 / (pp.G + pp.S)
+    a = make_engine(hip_api, pp, eps=0.0, gamma=g, flags=flags)
+    b = make_engine(hip_api, pp, eps=0.0, gamma=g, flags=flags | _capi.F_NO_TAIL_FUSE)
+    a2 = make_engine(hip_api, pp, eps=0.0, gamma=g, flags=flags | _capi.F_NO_GRAPH)
+    assert a.iterate_timed(1)["tail_fused"] == 1 and b.iterate_timed(1)["tail_fused"] == 0 and a2.iterate_timed(1)["tail_fused"] == 1
+    for n in (1, 5, 40, 150):
+        a.iterate(n)
+        b.iterate(n)
+        a2.iterate(n)
+        sa, sb, s2 = state_of(a), state_of(b), state_of(a2)
+        for k in sa:
+            if sa[k].size == 0:
+                continue
+            assert np.array_equal(sa[k], s2[k]), k
+            assert np.abs(sa[k] - sb[k]).max() <= 1e-9 * (1.0 + np.abs(sb[k]).max()), (n, k)
+        assert a.get_residuals()[3] == b.get_residuals()[3] == 2 + sum(x for x in (1, 5, 40, 150) if x <= n)
+    assert a.solver_failures() == 0 and b.solver_failures() == 0
+    # the stop test fires at the same iteration and freezes the state
+    c = make_engine(hip_api, pp, gamma=g, flags=flags, max_iters=5000)
+    d = make_engine(hip_api, pp, gamma=g, flags=flags | _capi.F_NO_TAIL_FUSE, max_iters=5000)
+    (nc, cc), (nd, cd) = c.iterate(5000), d.iterate(5000)
+    assert (nc, cc) == (nd, cd) and cc
+    assert c.iterate(10) == (0, True)
+    assert abs(c.get_consensus()[4] - d.get_consensus()[4]) <= 1e-9 * abs(d.get_consensus()[4])
 
 
 def test_hip_row_skipping_is_bit_identical(hip_api):
