@@ -8,8 +8,12 @@ A "step" is one ADMM iteration (all agent x-updates + consensus + dual update + 
 synthetic N-agent x T-timestep grid that is resident in HBM before the timed region starts.
 Prints ONE JSON line on rank 0:
   metric/value   agent-subproblem-updates per second, whole job (= agents x iterations / s)
-  roofline       the x-update launch: algorithmic bytes per launch / its HIP-event duration, over the timed region
-                 (`frac`) and in steady state; `traffic` = HBM bytes per launch from the committed PMC passes
+  roofline       the dominant kernel: algorithmic bytes per launch / its duration over the timed region (`frac`) and in steady
+                 state. On copper plates the whole iteration is ONE launch (consensus sum, dual step and stop test run in the
+                 launch's last block), and the duration is the per-iteration time of the graph replay itself — `frac` is then the
+                 whole-iteration fraction; otherwise HIP events net of the event overhead that makes the kernels of an
+                 iteration add up to that per-iteration time. `traffic` = HBM bytes per launch from the committed PMC passes
+                 (`traffic_source` names the file); `whole_iteration` = all kernels and gaps
   cpu_baseline   the oracle's exact mode (a "port", oracle/dopf_oracle.c) on the host cores, bounded sample
 Workloads (BASELINE.json `configs`): config1 = 1k gens + 100 storages x 24; config2 = 50k agents x 96
 (default: the largest single-GPU configuration); config4 = 1M agents x 24; config3 = 118-node/186-line
@@ -124,6 +128,9 @@ def self_launch(args, argv):
     # watchdog's business, and the second attempt then goes straight to torch
     modes = [args.comm] if args.comm != "auto" else ["auto", "torch"]
     last = ""
+    lost = []                           # attempts this watchdog had to end: they go into the final line (comm.transports_given_up)
+    t_end = time.time() + args.launch_timeout
+    os.environ.setdefault("DOPF_XCHG_TIMEOUT_MS", "5000")     # a lost peer ends a rank's exchange kernels after 5 s, not 20
     rest, skip = [], False
     for a in argv:                      # the children get the mode of the attempt: drop --comm X / --comm=X
         if skip:
@@ -139,17 +146,23 @@ def self_launch(args, argv):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + \
               rest + [f"--comm={mode}"]
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   DOPF_BENCH_LOST_ATTEMPTS=json.dumps(lost))
+        # the whole run has ONE budget (--launch-timeout): the first attempt may use 60 % of what is left, so that the
+        # fallback attempt (torch only) still fits under the caller's own limit
+        left = t_end - time.time()
+        budget = max(20.0, left * (0.6 if mode != modes[-1] else 1.0))
         p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=sys.stderr, env=env, start_new_session=True)
         try:
-            out, _ = p.communicate(timeout=args.launch_timeout)
+            out, _ = p.communicate(timeout=budget)
         except subprocess.TimeoutExpired:
             try:
                 os.killpg(p.pid, 9)          # exactly the process group started above
             except ProcessLookupError:
                 pass
             p.wait()
-            last = f"mode {mode}: no result within {args.launch_timeout} s"
+            last = f"mode {mode}: no result within {budget:.0f} s"
+            lost.append({"mode": mode, "why": f"killed at deadline ({budget:.0f} s)"})
             print(f"bench.py: {last}; trying the next mode", file=sys.stderr)
             continue
         lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
@@ -158,6 +171,7 @@ def self_launch(args, argv):
             sys.stdout.flush()
             return 0
         last = f"mode {mode}: exit code {p.returncode}"
+        lost.append({"mode": mode, "why": f"exit signal {-p.returncode}" if p.returncode < 0 else f"exit code {p.returncode}"})
         print(f"bench.py: {last}; trying the next mode", file=sys.stderr)
     print(f"bench.py: multi-GPU run failed ({last})", file=sys.stderr)
     return 1
@@ -177,6 +191,11 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="fork the storage kernel onto a side stream")
     ap.add_argument("--flags", type=int, default=0, help="DOPF_F_* bits (include/dopf.h), e.g. 16 = separate generator/storage launches")
     ap.add_argument("--no-also", action="store_true", help="skip the short side runs of the other single-GPU workloads")
+    ap.add_argument("--no-side", action="store_true", help="only the timed region and the kernel replay: no time-to-residual run, no central "
+                                                           "reference solve, no side workloads (profiling passes)")
+    ap.add_argument("--split-total", action="store_true",
+                    help="N > 1: the workload's agents are SPLIT over the ranks (BASELINE configs[3]/[4] name totals: 100k / 1M agents on 8 GPUs) "
+                         "instead of one full grid per rank; the line then says scaling = strong")
     ap.add_argument("--comm", default="auto", choices=["auto", "p2p", "lib", "lib-graph", "torch"],
                     help="N > 1: how the consensus vector is summed over the ranks. p2p = the library's peer exchange (one kernel "
                          "per iteration, direct stores into the peers' memory); lib = the library's own RCCL communicator, plain "
@@ -186,8 +205,11 @@ def main():
     ap.add_argument("--backend", default="nccl", help="--comm torch only: torch.distributed backend; nccl (= RCCL) is the product path, "
                                                       "gloo rehearses the multi-rank logic on a box with fewer GPUs than ranks")
     ap.add_argument("--force-sharded", action="store_true", help="debug: drive the sharded (all-reduce) path even on one rank")
-    ap.add_argument("--launch-timeout", type=float, default=420.0, help="self-launched multi-GPU run: seconds before a mode is given up")
+    ap.add_argument("--launch-timeout", type=float, default=150.0,
+                    help="self-launched multi-GPU run: budget in seconds for ALL attempts together (the first may use 60 %% of it)")
     args = ap.parse_args()
+    if args.no_side:
+        args.no_also = args.no_cpu_baseline = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -229,7 +251,7 @@ def main():
             # control plane only (unique id, demand sum, barriers, max of the times): gloo on host tensors.
             # The data path — the per-iteration consensus sum — is the library's own RCCL communicator.
             dist.init_process_group("gloo" if modes[0] in ("p2p", "lib", "lib-graph") else args.backend, rank=rank, world_size=world,
-                                    timeout=datetime.timedelta(seconds=600))
+                                    timeout=datetime.timedelta(seconds=max(30.0, min(120.0, 0.5 * args.launch_timeout))))
             ctl_dev = "cpu"
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -241,7 +263,12 @@ def main():
     # weak scaling: every rank owns one full grid of the workload (own seed), demand adds up
     base = make_problem(synth, args.workload, args.scale)
     own_demand = None
-    if world > 1:
+    split_total = args.split_total and world > 1
+    if split_total:
+        # BASELINE's configuration itself: its agents in `world` contiguous slices, one per rank (demand stays whole)
+        pp = base.shard(rank, world)
+        own_demand = np.asarray(base.demand, dtype=np.float64) / world      # (for rank 0's single-GPU kernel replay)
+    elif world > 1:
         cfg = dict(base.meta)
         pp = synth.synthetic_case(cfg["n_gen"], cfg["n_sto"], cfg["T"], N=cfg["N"], L=cfg["L"], seed=synth.SEED + rank)
         if cfg["L"] > 0:          # one network for everybody: rank 0's
@@ -253,7 +280,7 @@ def main():
     else:
         pp = base
     A_local = pp.G + pp.S
-    A_global = A_local * world
+    A_global = (base.G + base.S) if split_total else A_local * world
     gamma = args.gamma if args.gamma is not None else 1.0 / A_global
     # flow-consensus weight: the reference's literal 10 with lines makes every agent undo the whole line violation on
     # its own, an all-on/all-off 2-cycle for more than a few dozen agents whatever gamma is; it has to shrink with the
@@ -262,34 +289,42 @@ def main():
     comm_info = None
 
     def set_up(mode):
-        """-> (engine, step(n), sync(), close()) for one transport"""
+        """-> (engine, step(n), sync(), close()) for one transport. Two halves: everything a rank does on its own (engine, export of
+        its handle / unique id) comes first and is voted on; the host collectives that carry the handles run only when EVERY rank
+        got that far — a rank that failed alone would otherwise sit in a different collective than its peers until the
+        host channel's timeout."""
         if mode == "single":
             e = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank,
                                                                           flags=args.flags | (_capi.F_OVERLAP_AGENTS if args.overlap else 0)),
                              **pp.engine_kwargs())
             return e, e.iterate, e.sync, e.close
-        if mode == "p2p":
-            # peer exchange: the ranks' receive areas are mapped into each other (hipIpc handles over the host channel);
-            # the sum is one kernel of the iteration graph
-            e = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank, flags=args.flags,
-                                                                          n_agents_global=A_global), **pp.engine_kwargs())
-            hs = [None] * world
-            mine = e.xchg_export(world)
-            if world > 1:
-                dist.all_gather_object(hs, mine)
+        if mode in ("p2p", "lib", "lib-graph"):
+            e, mine, err = None, None, ""
+            try:
+                fl = args.flags | (_capi.F_COMM_GRAPH if mode == "lib-graph" else 0)
+                e = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank, flags=fl,
+                                                                              n_agents_global=A_global), **pp.engine_kwargs())
+                # p2p: the ranks' receive areas are mapped into each other (hipIpc handles over the host channel), the sum is one
+                # kernel of the iteration graph; lib: the library joins the ranks (RCCL) and owns the all-reduce
+                mine = e.xchg_export(world) if mode == "p2p" else (e.comm_unique_id() if rank == 0 else b"")
+            except Exception as ex:                 # noqa: BLE001
+                err = f"{type(ex).__name__}: {ex}"
+            if not all_ranks(not err):
+                if e is not None:
+                    e.close()
+                raise RuntimeError(err or "another rank failed before the handles were exchanged")
+            if mode == "p2p":
+                hs = [None] * world
+                if world > 1:
+                    dist.all_gather_object(hs, mine)
+                else:
+                    hs = [mine]
+                e.xchg_init(world, rank, hs)
             else:
-                hs = [mine]
-            e.xchg_init(world, rank, hs)
-            return e, e.iterate, e.sync, e.close
-        if mode in ("lib", "lib-graph"):
-            # every rank already holds its own grid; the library joins the ranks (RCCL) and owns the all-reduce
-            fl = args.flags | (_capi.F_COMM_GRAPH if mode == "lib-graph" else 0)
-            e = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank, flags=fl,
-                                                                          n_agents_global=A_global), **pp.engine_kwargs())
-            box = [e.comm_unique_id() if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(box, src=0)
-            e.comm_init(world, rank, box[0])
+                box = [mine if rank == 0 else None]
+                if world > 1:
+                    dist.broadcast_object_list(box, src=0)
+                e.comm_init(world, rank, box[0])
             return e, e.iterate, e.sync, e.close
         from decentralopf_jl_amd.sharded import ShardedADMM
         # every rank already holds its own grid: a 1-way "shard" of its local problem, global agent count
@@ -304,6 +339,13 @@ def main():
             dist.all_reduce(tens, op=dist.ReduceOp.SUM, group=data_group)
         sh._all_reduce = _all_reduce
         return sh.engine, sh.step, sh.sync, sh.engine.close
+
+    def all_ranks(ok):
+        if dist is None or world == 1:
+            return ok
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ctl_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
 
     def barrier():
         torch.cuda.synchronize()
@@ -325,13 +367,6 @@ def main():
                 _wm["b"] = _wm["a"] @ _wm["a"]
             torch.cuda.synchronize()
 
-    def all_ranks(ok):
-        if dist is None or world == 1:
-            return ok
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ctl_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        return bool(flag.item())
-
     def sums_are_right(eng):
         """The consensus sum itself, independently of the transport: every rank adds up its own units' injections on the host,
         the host channel (gloo) adds the ranks, and the result must be the injection every rank's device holds."""
@@ -346,7 +381,12 @@ def main():
         return float(np.abs(got - want).max()) <= 1e-9 * max(1.0, float(np.abs(want).max()))
 
     clock_warm()
+    side_errors = []                # errors of side solves and solver failures: reported in the line, never fatal
     comm_mode, given_up, dt = None, [], None
+    try:                            # attempts the launcher's watchdog had to end (killed at the deadline / died on a signal)
+        given_up += json.loads(os.environ.get("DOPF_BENCH_LOST_ATTEMPTS", "[]"))
+    except ValueError:
+        pass
     for mode in modes:
         # one transport: set-up, warm-up, checks, then the timed region; whatever goes wrong on any rank, all ranks move on
         why, closer = "", None
@@ -372,7 +412,12 @@ def main():
             try:
                 barrier()
                 t0 = time.perf_counter()
-                step(args.steps)
+                try:
+                    step(args.steps)
+                except _capi.DopfError as e:        # DOPF_E_SOLVER: the iterations ran, a storage root search hit its cap
+                    if "sub-problem" not in str(e):
+                        raise
+                    side_errors.append(f"timed region: {e}")
                 sync()
                 barrier()
                 dt = time.perf_counter() - t0
@@ -410,6 +455,7 @@ def main():
         comm_info = {"transport": f"torch.distributed ({args.backend}) all-reduce between dopf_local_update and dopf_apply_consensus",
                      "world": world, "captured_in_hipgraph": False}
     if comm_info is not None and given_up:
+        # in-place fallbacks of this run AND attempts the launcher's watchdog had to end (a retry must not hide an abort)
         comm_info["transports_given_up"] = given_up
 
     # Per-kernel durations, live, HIP events on the stream the kernels run on. The timed region above replays
@@ -454,13 +500,14 @@ def main():
         out = {
             "metric": "agent_subproblem_updates_per_sec", "value": A_global * args.steps / dt,
             "unit": "agent-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if split_total else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "description": desc, "agents_per_gpu": A_local,
                        "generators_per_gpu": pp.G, "storages_per_gpu": pp.S, "timesteps": pp.T,
                        "nodes": pp.N, "lines": pp.L, "gamma": gamma, "w_flow": w_flow, "w_prox": 1.0,
-                       "parallelism": f"agents sharded x{world}, 1 all-reduce of {(pp.N + 2 * pp.L) * pp.T + 1} f64 per iteration"
-                       if world > 1 else "single GPU"},
+                       "parallelism": (f"agents sharded x{world} ({'the configuration split over the ranks' if split_total else 'one full grid per rank'}), "
+                                       f"1 all-reduce of {(pp.N + 2 * pp.L) * pp.T + 1} f64 per iteration") if world > 1 else "single GPU",
+                       "agents_total": A_global},
             "iters_per_sec": args.steps / dt,
             "updates_per_sec_per_gpu": A_local * args.steps / dt,
             "solver_failures": int(fails),
@@ -471,28 +518,49 @@ def main():
             out["comm"] = comm_info
         if args.scale != 1.0:
             out["invalid"] = "scaled-down workload (debug run)"
+        it_ms = 1e3 * dt / args.steps
+        whole_b = gen_b + sto_b + shared_b
         if timing is not None:
-            # an event pair costs a fixed few microseconds even with nothing between (empty_ms): net it out
-            k_ms = max(timing["gen_ms"] - timing["empty_ms"], 1e-6)
             fused = bool(timing.get("agents_fused"))
+            tail = bool(timing.get("tail_fused"))
             pair = pp.L == 0 and pp.T % 2 == 0
             bs = 256 if fused else 512
             rows = bs // (pp.T // 2) if pair else 1
             row_skip = pair and not (args.flags & _capi.F_NO_ROW_SKIP) and max(rows, -(-pp.G // 2048)) >= 8 * rows    # as dopf_create decides
             if fused:       # ONE launch does every x-update: generators and storages
-                kname, alg_b = "k_agents", gen_b + sto_b + shared_b
+                kname, alg_b = "k_agents", whole_b
             else:
                 kname = ("k_gen_update_pair_skip" if row_skip else "k_gen_update_pair") if pair else "k_gen_update"
                 alg_b = gen_b + shared_b
-            traffic = None       # HBM bytes per launch from the committed PMC passes (scripts/profile.sh)
-            for tag in ("r02", "r01"):
+            # Kernel durations. An event pair adds a fixed cost to what it brackets (`empty_ms` is an upper bound of it: part
+            # of an empty pair's cost overlaps with a real kernel's own launch). The overhead used here is the one that makes
+            # the kernels of an iteration ADD UP to the per-iteration time of the graph replay (no events in there): live,
+            # no constant. rocprofv3's per-kernel durations agree with it (profiles/).
+            launched = ["gen_ms"] + ([] if fused else ["sto_ms"]) + (["tables_ms", "slack_ms"] if pp.L > 0 else []) + \
+                       ([] if tail else ["reduce_ms", "dual_ms"])
+
+            def overhead(tm, per_iter_ms):
+                if world > 1:            # (the replay is one rank's grid without the exchange: nothing to calibrate against)
+                    return 0.5 * tm["empty_ms"]
+                return min(tm["empty_ms"], max(0.0, (sum(tm[k] for k in launched) - per_iter_ms) / len(launched)))
+            ov = overhead(timing, it_ms)
+            one_launch = fused and tail and world == 1
+            # one launch per iteration: the per-iteration time of the graph replay IS the launch (plus its one kernel boundary)
+            k_ms = it_ms if one_launch else max(timing["gen_ms"] - ov, 1e-6)
+            traffic, traffic_source = None, None       # HBM bytes per launch from the committed PMC passes (scripts/profile.sh)
+            for tag in ("r03", "r02", "r01"):
                 pmc_file = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
                 if traffic is None and os.path.exists(pmc_file):
                     recs = json.load(open(pmc_file)).get(args.workload, {})
                     rec = next((r for k, r in sorted(recs.items()) if k.startswith(kname) and r.get("FETCH_SIZE") is not None), None)
                     if rec:        # gfx950: FETCH_SIZE counts half of a streaming read (MI355X_MICROARCH.md, HBM); unit KiB
                         traffic = (2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0
-            ks_ms = max(steady["gen_ms"] - steady["empty_ms"], 1e-6)
+                        traffic_source = (f"profiles/{tag}_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the default command "
+                                          f"(`python bench.py --workload {args.workload}`), mean per launch — not measured in this run")
+            # steady state: its own per-iteration time is not measured with the graph; same overhead as the timed region
+            ks_ms = max(steady["gen_ms"] - ov, 1e-6)
+            if one_launch:
+                ks_ms = max(steady["iter_ms"] - (timing["iter_ms"] - it_ms), 1e-6)
             # Row skipping moves fewer bytes than the 16T+20 B/update model: algorithmic bytes / time would exceed what the
             # memory system did (and the 8 TB/s peak). The roofline fraction is then taken from the MEASURED traffic.
             basis_b, basis = alg_b, "algorithmic bytes (SURVEY.md 8d model)"
@@ -501,91 +569,114 @@ def main():
                                            "model's bytes are not moved")
             ach = basis_b / (k_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": PEAK_GBPS,
-                               "unit": "GB/s", "frac": ach / PEAK_GBPS, "traffic": traffic,
+                               "unit": "GB/s", "frac": ach / PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                                "bytes_basis": basis,
                                "algorithmic_bytes_per_launch": alg_b,
-                               "kernel_ms": k_ms, "kernel_ms_with_event_overhead": timing["gen_ms"],
-                               "window": f"mean over the timed region's iterations ({args.warmup + 1}..{args.warmup + args.steps} from the zero "
-                                         "state, replayed with HIP events on the kernels' stream)",
+                               "kernel_ms": k_ms,
+                               "kernel_ms_basis": ("per-iteration time of the timed region's graph replay: the iteration is this ONE launch (x-updates, "
+                                                   "consensus sum, dual step, stop test) plus its kernel boundary") if one_launch else
+                                                  ("HIP events on the kernels' stream over the timed region's iterations (replayed), net of the event "
+                                                   "overhead that makes the iteration's kernels add up to the graph replay's per-iteration time"),
+                               "kernel_ms_events_raw": timing["gen_ms"], "event_overhead_ms": ov, "empty_event_pair_ms": timing["empty_ms"],
+                               "window": f"the timed region: iterations {args.warmup + 1}..{args.warmup + args.steps} from the zero state",
                                "steady_state": {"kernel_ms": ks_ms, "achieved": basis_b / (ks_ms * 1e-3) / 1e9,
                                                 "frac": basis_b / (ks_ms * 1e-3) / 1e9 / PEAK_GBPS,
-                                                "window": f"{steady['iters']} iterations from iteration {steady_from + 1} on"}}
+                                                "window": f"{steady['iters']} iterations from iteration {steady_from + 1} on"},
+                               "whole_iteration": {"bytes": whole_b, "ms": it_ms, "achieved": whole_b / it_ms * 1e-6,
+                                                   "frac": whole_b / it_ms * 1e-6 / PEAK_GBPS,
+                                                   "what": "algorithmic bytes of one iteration / per-iteration time of the timed region "
+                                                           "(all launches and the gaps between them)"}}
             if row_skip:
                 out["roofline"]["algorithmic_GBps"] = alg_b / (k_ms * 1e-3) / 1e9
             if fused:
                 out["roofline"]["what"] = ("all x-updates of an iteration in one launch: generator blocks stream P (HBM bound), storage "
-                                           "blocks run the active-set SoC solve (fp64 VALU bound) on the same CUs")
+                                           "blocks run the active-set SoC solve (fp64 VALU bound) on the same CUs" +
+                                           ("; its last block adds up the blocks' sums and runs the dual step and the stop test" if tail else ""))
             out["kernels_ms"] = {k: v for k, v in timing.items() if k.endswith("_ms")}
             out["kernels_ms_steady_state"] = {k: v for k, v in steady.items() if k.endswith("_ms")}
-            out["agents_fused"] = fused
+            out["agents_fused"], out["tail_fused"] = fused, tail
             if not fused:
-                s_ms = max(timing["sto_ms"] - timing["empty_ms"], 1e-6)
-                out["storage_kernel"] = {"kernel": "k_sto (active-set solve; scan kernel for what it leaves over)" if pp.L == 0 else "k_sto_warm + k_sto_update",
+                s_ms = max(timing["sto_ms"] - ov, 1e-6)
+                out["storage_kernel"] = {"kernel": "k_sto (active-set solve; scan kernel for what it leaves over" +
+                                                   ("; carries the iteration's tail block)" if tail else ")") if pp.L == 0 else "k_sto_warm + k_sto_update",
                                          "bound": "fp64 VALU (segmented Newton + certificate), not HBM",
                                          "algorithmic_bytes_per_launch": sto_b, "kernel_ms": s_ms,
-                                         "achieved_GBps": sto_b / s_ms * 1e-6}
-            if fused and world == 1 and not args.force_sharded:
+                                         "achieved_GBps": sto_b / s_ms * 1e-6, "frac_of_hbm_peak": sto_b / s_ms * 1e-6 / PEAK_GBPS}
+            if fused and world == 1 and not args.force_sharded and not args.no_side:
                 # the two halves of k_agents on their own (separate launches, DOPF_F_NO_FUSE), steady state: the generator
                 # sweep is the HBM-bound part, the storage solve the VALU-bound one
                 ex = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=0.0, device=local_rank,
-                                                                               flags=args.flags | _capi.F_NO_FUSE), **pp.engine_kwargs())
+                                                                               flags=args.flags | _capi.F_NO_FUSE | _capi.F_NO_TAIL_FUSE), **pp.engine_kwargs())
                 clock_warm()
                 ex.iterate(steady_from)
                 tx = ex.iterate_timed(steady["iters"])
                 ex.close()
-                g_ms, s_ms2 = max(tx["gen_ms"] - tx["empty_ms"], 1e-6), max(tx["sto_ms"] - tx["empty_ms"], 1e-6)
+                g_ms, s_ms2 = max(tx["gen_ms"] - ov, 1e-6), max(tx["sto_ms"] - ov, 1e-6)
                 out["roofline"]["parts_as_separate_launches"] = {
                     "k_gen_update_pair": {"kernel_ms": g_ms, "algorithmic_bytes_per_launch": gen_b + shared_b,
                                           "achieved": (gen_b + shared_b) / g_ms * 1e-6, "frac": (gen_b + shared_b) / g_ms * 1e-6 / PEAK_GBPS},
                     "k_sto": {"kernel_ms": s_ms2, "algorithmic_bytes_per_launch": sto_b,
                               "achieved": sto_b / s_ms2 * 1e-6, "frac": sto_b / s_ms2 * 1e-6 / PEAK_GBPS},
-                    "window": "as the steady state above"}
-            whole = (gen_b + sto_b + shared_b) / (dt / args.steps) / 1e9
-            out["whole_iteration_GBps"] = whole
-            out["whole_iteration_frac_of_peak"] = whole / PEAK_GBPS
-        if not sharded:
-            # the other half of BASELINE's metric: wall time until every |dual change| < 1e-3, from the zero state
-            budget = int(max(64, min(100000, 10.0 * args.steps / dt)))     # at most ~10 s of iterations
-            e2 = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=1e-3, max_iters=budget, device=local_rank, flags=args.flags),
-                              **pp.engine_kwargs())
-            clock_warm()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            done2, conv2 = 0, False
-            while not conv2 and done2 < budget:        # short slices: (almost) no launches after the stop test fires
-                d_, conv2 = e2.iterate(min(32, budget - done2))
-                done2 += d_
-                if d_ == 0:
-                    break
-            t2 = time.perf_counter() - t0
-            out["time_to_1e-3_residual"] = {"seconds": t2 if conv2 else None, "iterations": done2, "converged": bool(conv2),
-                                            "iteration_cap": budget, "total_cost": e2.get_consensus()[4]}
-            # BASELINE's third target: converged objective within 1e-3 of the central optimum (fixtures: HiGHS solves of
-            # the same seed-stable cases, tests/golden/make_synthetic_optima.py)
-            opt_file = os.path.join(ROOT, "tests", "golden", "synthetic_optima.json")
-            if conv2 and args.scale == 1.0 and os.path.exists(opt_file):
-                opt = json.load(open(opt_file)).get(args.workload)
-                if opt and (opt["G"], opt["S"], opt["T"]) == (pp.G, pp.S, pp.T) and args.w_flow is None:
-                    out["time_to_1e-3_residual"]["central_lp_optimum"] = opt["objective"]
-                    out["time_to_1e-3_residual"]["relative_gap_to_central_lp"] = \
-                        abs(out["time_to_1e-3_residual"]["total_cost"] - opt["objective"]) / opt["objective"]
-            e2.close()
-            # the central reference solved on the device (dopf_central_solve = src/opf_central_reference.jl as a first-order LP
-            # solve): the same target without a host LP
-            t0 = time.perf_counter()
-            cr = _capi.central_solve(_capi.hip_api(), tol=1e-7, max_iters=100000,
-                                     params=_capi.default_params(device=local_rank), **pp.engine_kwargs())
-            tcr = time.perf_counter() - t0
-            out["central_reference_on_device"] = {"objective": cr["objective"], "dual_objective": cr["dual_objective"],
-                                                  "primal_infeasibility": cr["primal_infeasibility"], "gap": cr["gap"],
-                                                  "iterations": cr["iterations"], "converged": cr["converged"], "seconds": tcr}
-            if conv2 and cr["converged"]:
-                out["time_to_1e-3_residual"]["relative_gap_to_device_central_reference"] = \
-                    abs(out["time_to_1e-3_residual"]["total_cost"] - cr["objective"]) / cr["objective"]
+                    "window": "as the steady state above; partial rows + k_reduce + dual kernel (DOPF_F_NO_TAIL_FUSE)"}
+            out["whole_iteration_GBps"] = whole_b / it_ms * 1e-6
+            out["whole_iteration_frac_of_peak"] = whole_b / it_ms * 1e-6 / PEAK_GBPS
+        if not sharded and not args.no_side:
+            try:
+                # the other half of BASELINE's metric: wall time until every |dual change| < 1e-3, from the zero state
+                budget = int(max(64, min(100000, 10.0 * args.steps / dt)))     # at most ~10 s of iterations
+                e2 = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gamma, w_flow=w_flow, eps=1e-3, max_iters=budget, device=local_rank, flags=args.flags),
+                                  **pp.engine_kwargs())
+                clock_warm()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                done2, conv2 = 0, False
+                while not conv2 and done2 < budget:        # short slices: (almost) no launches after the stop test fires
+                    d_, conv2 = e2.iterate(min(32, budget - done2))
+                    done2 += d_
+                    if d_ == 0:
+                        break
+                t2 = time.perf_counter() - t0
+                out["time_to_1e-3_residual"] = {"seconds": t2 if conv2 else None, "iterations": done2, "converged": bool(conv2),
+                                                "iteration_cap": budget, "total_cost": e2.get_consensus()[4]}
+                # BASELINE's third target: converged objective within 1e-3 of the central optimum (fixtures: HiGHS solves of
+                # the same seed-stable cases, tests/golden/make_synthetic_optima.py)
+                opt_file = os.path.join(ROOT, "tests", "golden", "synthetic_optima.json")
+                if conv2 and args.scale == 1.0 and os.path.exists(opt_file):
+                    opt = json.load(open(opt_file)).get(args.workload)
+                    if opt and (opt["G"], opt["S"], opt["T"]) == (pp.G, pp.S, pp.T) and args.w_flow is None:
+                        out["time_to_1e-3_residual"]["central_lp_optimum"] = opt["objective"]
+                        out["time_to_1e-3_residual"]["relative_gap_to_central_lp"] = \
+                            abs(out["time_to_1e-3_residual"]["total_cost"] - opt["objective"]) / opt["objective"]
+                e2.close()
+                # the central reference solved on the device (dopf_central_solve = src/opf_central_reference.jl as a first-order LP
+                # solve): the same target without a host LP
+                t0 = time.perf_counter()
+                cr = _capi.central_solve(_capi.hip_api(), tol=1e-7, max_iters=100000,
+                                         params=_capi.default_params(device=local_rank), **pp.engine_kwargs())
+                tcr = time.perf_counter() - t0
+                out["central_reference_on_device"] = {"objective": cr["objective"], "dual_objective": cr["dual_objective"],
+                                                      "primal_infeasibility": cr["primal_infeasibility"], "gap": cr["gap"],
+                                                      "iterations": cr["iterations"], "converged": cr["converged"], "seconds": tcr}
+                if conv2 and cr["converged"]:
+                    out["time_to_1e-3_residual"]["relative_gap_to_device_central_reference"] = \
+                        abs(out["time_to_1e-3_residual"]["total_cost"] - cr["objective"]) / cr["objective"]
+            except _capi.DopfError as e:
+                side_errors.append(f"time-to-residual / central reference: {e}")
         if not sharded and not args.no_also and args.scale == 1.0:
             # the other BASELINE configurations that fit one GPU, same engine, short runs (reported, not the metric)
             also = []
-            for wl in ("config1", "config4", "config2", "config3-share", "config3"):
+            def pmc_iteration_traffic(wl_):
+                """HBM bytes of ONE iteration (all kernels of the chain) from the committed PMC passes, or None"""
+                for tag in ("r03", "r02"):
+                    f_ = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
+                    if os.path.exists(f_):
+                        recs = {k: r for k, r in json.load(open(f_)).get(wl_, {}).items()
+                                if k.startswith(("k_agents", "k_gen_update", "k_sto", "k_reduce", "k_dual_price_small<true", "k_dual_price_t1024<true",
+                                                 "k_tables", "k_slack")) and r.get("FETCH_SIZE") is not None and r.get("WRITE_SIZE") is not None}
+                        if recs:
+                            return sum((2.0 * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024.0 for r in recs.values()), f"profiles/{tag}_pmc.json"
+                return None, None
+            for wl in ("config1", "config4", "config2", "config3-share", "config3", "config4x2"):
                 if wl == args.workload:
                     continue
                 ppx = make_problem(synth, wl)
@@ -605,7 +696,16 @@ def main():
                 also.append({"workload": wl, "agents": Ax, "timesteps": ppx.T, "iters_per_sec": nx / tx,
                              "agent_updates_per_sec": Ax * nx / tx, "ms_per_step": 1e3 * tx / nx,
                              "whole_iteration_GBps": (gb + sb + shb) / (tx / nx) / 1e9,
+                             "whole_iteration_frac_of_peak": (gb + sb + shb) / (tx / nx) / 1e9 / PEAK_GBPS,
                              "window": f"iterations {wx + 1}..{wx + nx}"})
+                if wl in ("config4", "config4x2"):
+                    # row skipping moves fewer bytes than the model; config4x2's arrays (384 MB of P) do not fit the 256 MiB Infinity
+                    # Cache: there "fraction of HBM peak" means HBM. Bytes from the committed PMC passes, time from this run.
+                    trf, src = pmc_iteration_traffic(wl)
+                    if trf is not None:
+                        also[-1]["hbm_traffic_per_iteration"] = trf
+                        also[-1]["hbm_traffic_frac_of_peak"] = trf / (tx / nx) / 1e9 / PEAK_GBPS
+                        also[-1]["hbm_traffic_source"] = src + " (all kernels of an iteration; not measured in this run)"
                 ex.close()
             # BASELINE configs[1] names "rho = 1.0" (rho there = the reference's gamma): the iteration RATE with that literal
             # penalty (it does not converge at this size: Jacobi with a fixed prox weight)
@@ -646,6 +746,8 @@ def main():
             out["config4_penalty_sweep"] = penalty_sweep(make_problem(synth, "config4"), (0.3, 1.0, 1.5, 3.0), 2500)
             if args.workload == "config2":
                 out["config2_penalty_sweep"] = penalty_sweep(pp, (0.3, 1.0, 1.5, 2.0), 2000)
+        if side_errors:
+            out["errors"] = side_errors
         if not sharded and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pp, gamma, w_flow, synth)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

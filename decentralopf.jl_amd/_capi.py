@@ -178,6 +178,12 @@ def _pin_hip_runtime():
     if "torch" in sys.modules:
         return                          # its runtime is loaded already; ours will bind to it
     try:
+        with open("/proc/self/maps") as f:
+            if "libamdhip64" in f.read():
+                return                  # a HIP runtime is mapped already (whoever loaded it): never add a second one
+    except OSError:
+        pass
+    try:
         import importlib.util
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):

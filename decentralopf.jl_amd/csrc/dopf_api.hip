@@ -264,6 +264,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         return fail(nullptr, DOPF_E_UNSUPPORTED, "storage kernel supports T <= 512 (got %d)", p->T);
     if (2 * p->L > 4096) return fail(nullptr, DOPF_E_UNSUPPORTED, "table kernel supports L <= 2048 (got %d)", p->L);   // 4 * 2L doubles of LDS
 
+    if (int rc1 = check_one_runtime(nullptr)) return rc1;
     int ndev = 0;
     hipError_t e0 = hipGetDeviceCount(&ndev);
     if (e0 != hipSuccess || ndev < 1)

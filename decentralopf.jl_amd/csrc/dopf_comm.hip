@@ -23,14 +23,18 @@
 // transport that lets several shards share ONE device (RCCL refuses two ranks on a device), which is how
 // the sharding logic of dopf_multi_* is tested on a one-GPU box.
 #include <dlfcn.h>
+#include <link.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <thread>
+#include <vector>
 
 #include "dopf_ctx.h"
 
@@ -57,19 +61,72 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    char err[256] = {0};
+    char err[512] = {0};
+    int code = DOPF_E_DEVICE;      // what a caller returns with `err`: DOPF_E_UNSUPPORTED for "two copies mapped"
 };
 
 Rccl g_rccl;
 std::once_flag g_rccl_once;
 
+// What is mapped into this process: every librccl, every HIP runtime, and the directory a PyTorch build lives in.
+struct Mapped {
+    std::vector<std::string> rccl, hip;
+    std::string torch_dir;
+};
+
+int scan_cb(struct dl_phdr_info *info, size_t, void *data)
+{
+    Mapped *m = static_cast<Mapped *>(data);
+    const char *path = info->dlpi_name;
+    if (!path || !*path) return 0;
+    const char *base = strrchr(path, '/');
+    base = base ? base + 1 : path;
+    auto add = [](std::vector<std::string> &v, const char *p_) {
+        for (const auto &x : v) if (x == p_) return;
+        v.emplace_back(p_);
+    };
+    if (strncmp(base, "librccl.so", 10) == 0) add(m->rccl, path);
+    if (strncmp(base, "libamdhip64.so", 14) == 0) add(m->hip, path);
+    if (strncmp(base, "libtorch_hip.so", 15) == 0 || strncmp(base, "libc10_hip.so", 13) == 0) m->torch_dir.assign(path, (size_t)(base - path));
+    return 0;
+}
+
+Mapped scan_mapped()
+{
+    Mapped m;
+    dl_iterate_phdr(scan_cb, &m);
+    return m;
+}
+
+// One RCCL per process, and the one that belongs to the HIP runtime the process runs on. PyTorch's wheels bundle their
+// own librccl.so next to their own libamdhip64.so; a system RCCL (built against the system's runtime) bound to that
+// bundled runtime, or two RCCLs side by side, end in heap corruption (round 2's abort inside dopf_create: the library
+// had dlopen'ed the system's copy, PyTorch's arrived later). So: a copy that is mapped already is THE copy; otherwise
+// the librccl.so next to the mapped HIP runtime or next to libtorch_hip.so (the copy PyTorch would load later); only a
+// process without any of that (a C or Julia host on the system's ROCm) gets the system's library.
 void load_rccl()
 {
-    // A process that already carries RCCL (PyTorch ships its own copy) gets that very library; otherwise the
-    // system's is loaded privately (RTLD_LOCAL: a second copy loaded later by someone else must not see our symbols
-    // interposed over its own).
+    const Mapped m = scan_mapped();
+    if (m.rccl.size() > 1) {
+        snprintf(g_rccl.err, sizeof g_rccl.err, "two copies of RCCL are mapped into this process (%s, %s): refusing to pick one",
+                 m.rccl[0].c_str(), m.rccl[1].c_str());
+        g_rccl.code = DOPF_E_UNSUPPORTED;
+        return;
+    }
+    if (m.rccl.size() == 1) g_rccl.lib = dlopen(m.rccl[0].c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    if (!g_rccl.lib) {
+        std::vector<std::string> next_to;
+        if (!m.torch_dir.empty()) next_to.push_back(m.torch_dir);
+        for (const auto &h : m.hip) next_to.push_back(h.substr(0, h.rfind('/') + 1));
+        for (const auto &d : next_to) {
+            for (const char *n : {"librccl.so", "librccl.so.1"}) {
+                if (g_rccl.lib) break;
+                const std::string cand = d + n;
+                if (access(cand.c_str(), R_OK) == 0) g_rccl.lib = dlopen(cand.c_str(), RTLD_NOW | RTLD_LOCAL);
+            }
+        }
+    }
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (int k = 0; k < 2 && !g_rccl.lib; ++k) g_rccl.lib = dlopen(names[k], RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
     for (const char *n : names) {
         if (g_rccl.lib) break;
         g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
@@ -90,8 +147,39 @@ void load_rccl()
 const Rccl *rccl()
 {
     std::call_once(g_rccl_once, load_rccl);
+    if (g_rccl.lib) {
+        // somebody may have loaded a second copy since (a PyTorch imported after the library had to load RCCL on a system
+        // runtime): say so instead of running two collectives libraries in one address space
+        const Mapped m = scan_mapped();
+        if (m.rccl.size() > 1) {
+            snprintf(g_rccl.err, sizeof g_rccl.err, "two copies of RCCL are mapped into this process (%s, %s): load PyTorch (or whatever brings "
+                     "its own RCCL) before the first dopf_comm_* / dopf_multi_* call", m.rccl[0].c_str(), m.rccl[1].c_str());
+            g_rccl.code = DOPF_E_UNSUPPORTED;
+            return nullptr;
+        }
+    }
     return g_rccl.lib ? &g_rccl : nullptr;
 }
+
+}  // namespace
+
+namespace dopf {
+
+// dopf_create: more than one HIP runtime in the process means one of them cannot see the devices (and anything bound to
+// the other one is an ABI mismatch): a clear message instead of "no device" or a crash later
+int check_one_runtime(dopf_ctx *c)
+{
+    const Mapped m = scan_mapped();
+    if (m.hip.size() > 1)
+        return fail(c, DOPF_E_UNSUPPORTED, "two HIP runtimes are mapped into this process (%s, %s): load the one the process is to use "
+                    "first (PyTorch bundles its own; decentralopf_jl_amd._capi.hip_api() pins it before libdopf_hip.so is loaded)",
+                    m.hip[0].c_str(), m.hip[1].c_str());
+    return DOPF_OK;
+}
+
+}  // namespace dopf
+
+namespace {
 
 }  // namespace
 
@@ -173,14 +261,17 @@ int for_each_shard(dopf_multi *m, F f)
 }
 
 // ---- peer exchange set-up -------------------------------------------------------------------------------------
-// layout of a rank's receive area: [world] hello words | [2][world][chunks] flags | (256-byte aligned) [2][world][n] doubles
+// layout of a rank's receive area: [world] hello words | [2][world][chunks] flags | [2][chunks] sum flags |
+// (256-byte aligned) [2][world][n] doubles | [2][n] summed chunks
 struct XchgLayout {
-    size_t n, nchunks, flags_off, data_off, bytes;
+    size_t n, nchunks, flags_off, sflags_off, data_off, sum_off, bytes;
     XchgLayout(size_t n_, int world) : n(n_), nchunks((n_ + kXchgChunk - 1) / kXchgChunk)
     {
         flags_off = (size_t)kXchgMaxWorld * sizeof(unsigned long long);
-        data_off = (flags_off + 2 * (size_t)world * nchunks * sizeof(unsigned long long) + 255) / 256 * 256;
-        bytes = data_off + 2 * (size_t)world * n * sizeof(double);
+        sflags_off = flags_off + 2 * (size_t)world * nchunks * sizeof(unsigned long long);
+        data_off = (sflags_off + 2 * nchunks * sizeof(unsigned long long) + 255) / 256 * 256;
+        sum_off = data_off + 2 * (size_t)world * n * sizeof(double);
+        bytes = sum_off + 2 * n * sizeof(double);
     }
 };
 
@@ -207,9 +298,15 @@ void xchg_fill_view(dopf_ctx *c, dopf_comm_state *cs, int world, int rank, void 
     const XchgLayout lay((size_t)dopf_consensus_size(c), world);
     XchgView &x = cs->xv;
     x.world = world; x.me = rank; x.nchunks = (int)lay.nchunks; x.n = lay.n; x.timeout_ticks = xchg_timeout_ticks();
+    // more than one chunk per rank: every chunk has an owner that adds the ranks' copies and hands the sum to everybody
+    // (2 n doubles in and out per rank and iteration instead of world x n)
+    x.rs = ((int)lay.nchunks > world && world > 1 && !getenv("DOPF_XCHG_ALLGATHER")) ? 1 : 0;
+    if (getenv("DOPF_XCHG_REDUCE_SCATTER")) x.rs = 1;            // (tests: the owner form on small vectors and at world 1)
     for (int r = 0; r < world; ++r) {
         x.flags[r] = reinterpret_cast<unsigned long long *>((char *)areas[r] + lay.flags_off);
+        x.sflags[r] = reinterpret_cast<unsigned long long *>((char *)areas[r] + lay.sflags_off);
         x.data[r] = reinterpret_cast<double *>((char *)areas[r] + lay.data_off);
+        x.sum[r] = reinterpret_cast<double *>((char *)areas[r] + lay.sum_off);
     }
 }
 
@@ -259,7 +356,11 @@ int dopf_xchg_init(dopf_ctx *c, int32_t world, int32_t rank, const void *handles
     xchg_fill_view(c, cs, world, rank, areas);
     // rendezvous: say hello in every peer's area, wait until every peer has said hello here — from then on all areas
     // are mapped everywhere and the ranks are at most a host call apart
-    const unsigned long long one = 1ull;
+    // The hello word carries the rank's iteration count (+1): the exchange's sequence numbers and slot parities are
+    // derived from it, so ranks that join with different counts would read each other's other slot, whose older flag
+    // already passes — refused here instead.
+    if (int rcs = read_status(c)) return rcs;
+    const unsigned long long one = (unsigned long long)c->host_st.iters_total + 1ull;
     for (int r = 0; r < world; ++r)
         HIPCHK(c, hipMemcpy((char *)areas[r] + (size_t)rank * sizeof one, &one, sizeof one, hipMemcpyHostToDevice));
     double wait_s = 120.0;
@@ -269,8 +370,14 @@ int dopf_xchg_init(dopf_ctx *c, int32_t world, int32_t rank, const void *handles
         unsigned long long hello[kXchgMaxWorld];
         HIPCHK(c, hipMemcpy(hello, cs->xbuf, sizeof hello, hipMemcpyDeviceToHost));
         int seen = 0;
-        for (int r = 0; r < world; ++r) seen += hello[r] == 1ull;
-        if (seen == world) break;
+        for (int r = 0; r < world; ++r) seen += hello[r] != 0ull;
+        if (seen == world) {
+            for (int r = 0; r < world; ++r)
+                if (hello[r] != one)
+                    return fail(c, DOPF_E_INVALID, "peer exchange: rank %d joins after %llu iterations, this rank after %llu — the ranks "
+                                "must join with the same iteration count", r, hello[r] - 1ull, one - 1ull);
+            break;
+        }
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_s)
             return fail(c, DOPF_E_DEVICE, "peer exchange: %d of %d ranks showed up within %.0f s", seen, world, wait_s);
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
@@ -283,7 +390,7 @@ int dopf_comm_unique_id(void *id128)
 {
     if (!id128) return DOPF_E_INVALID;
     const Rccl *r = rccl();
-    if (!r) return fail(nullptr, DOPF_E_DEVICE, "%s", g_rccl.err);
+    if (!r) return fail(nullptr, g_rccl.code, "%s", g_rccl.err);
     ncclUniqueId id;
     const ncclResult_t e = r->GetUniqueId(&id);
     if (e != ncclSuccess) return fail(nullptr, DOPF_E_DEVICE, "ncclGetUniqueId: %s", r->GetErrorString(e));
@@ -297,7 +404,7 @@ int dopf_comm_init(dopf_ctx *c, int32_t world, int32_t rank, const void *id128)
     if (!c || world < 1 || rank < 0 || rank >= world || !id128) return fail(c, DOPF_E_INVALID, "bad argument");
     if (c->comm) return fail(c, DOPF_E_INVALID, "context already has a communicator");
     const Rccl *r = rccl();
-    if (!r) return fail(c, DOPF_E_DEVICE, "%s", g_rccl.err);
+    if (!r) return fail(c, g_rccl.code, "%s", g_rccl.err);
     DeviceGuard guard(c->device);
     HIPCHK(c, hipStreamSynchronize(c->main));
     ncclUniqueId id;
@@ -350,7 +457,7 @@ int dopf_multi_create(dopf_multi **out, const dopf_problem *p, const dopf_params
     const Rccl *r = nullptr;
     if (!host_sum && !p2p && n_gpus > 1) {
         r = rccl();
-        if (!r) return mfail(nullptr, DOPF_E_DEVICE, g_rccl.err);
+        if (!r) return mfail(nullptr, g_rccl.code, g_rccl.err);
     }
     dopf_multi *m = new (std::nothrow) dopf_multi;
     if (!m) return mfail(nullptr, DOPF_E_NOMEM, "out of host memory");

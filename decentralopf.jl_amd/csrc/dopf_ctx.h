@@ -36,6 +36,7 @@ void enqueue_apply(dopf_ctx *c, bool single, const XchgView *xd = nullptr);
 void drop_graphs(dopf_ctx *c);
 int read_status(dopf_ctx *c);
 // dopf_comm.hip
+int check_one_runtime(dopf_ctx *c);           // DOPF_E_UNSUPPORTED when two HIP runtimes are mapped into the process
 int comm_enqueue_allreduce(dopf_ctx *c);      // sum of the consensus buffer over the ranks, on the context's stream
 void comm_release(dopf_ctx *c);
 int comm_world(const dopf_ctx *c);             // ranks of the context's communicator (1 without one)

@@ -205,10 +205,13 @@ constexpr int kXchgMaxWorld = 16;
 constexpr int kXchgChunk = 2048;                // doubles per block
 struct XchgView {
     int world, me, nchunks;
+    int rs;                                     // 1: reduce-scatter + all-gather form (k_xchg_rs: vectors of more than one chunk per rank)
     unsigned long long n;                       // doubles in the consensus vector
     unsigned long long timeout_ticks;           // wall_clock64 ticks (100 MHz) a block waits for its peers
     double *data[kXchgMaxWorld];
     unsigned long long *flags[kXchgMaxWorld];
+    double *sum[kXchgMaxWorld];                 // [2 parities][n]: the summed chunks, written by each chunk's owner (rs form)
+    unsigned long long *sflags[kXchgMaxWorld];  // [2][chunks]
 };
 void launch_xchg(const DevView &v, const XchgView &x, hipStream_t s);   // cons <- sum over ranks of cons (rank order)
 void launch_dual(const DevView &v, hipStream_t s, const XchgView *xd = nullptr);   // xd: peer exchange inside the one-block kernel

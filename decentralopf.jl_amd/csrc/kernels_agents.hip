@@ -1317,8 +1317,8 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
     Item it;
     if (v.stoChunk > 0) { it.a0 = blk * v.stoChunk; it.a1 = min(v.S, it.a0 + v.stoChunk); it.node = 0; }
     else it = v.sto_items[blk];
-    // `halt`: the caller's halt word, loaded but not yet looked at, so that it travels with the item (uniform; -1 = halted)
-    if (halt) return -1;
+    // `halt`: the caller's halt word, loaded but not yet looked at: it travels with the first storage's rows (looked at
+    // below, once those loads have been issued; nothing is stored before that. Uniform; -1 = halted)
     const int T = v.T, N = v.N;
     const double w = v.w_prox, gam = v.gamma;
     const double a0 = w + gam, ia0 = 1.0 / a0, idet0 = 1.0 / (a0 * a0 - gam * gam), s20 = 2.0 / (a0 + gam);
@@ -1355,7 +1355,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
         }
     }
 #ifdef DOPF_STATS
-    unsigned long long st_rounds = 0, st_newton = 0, cyc[6] = {0, 0, 0, 0, 0, 0}, tq = 0;
+    unsigned long long st_rounds = 0, st_newton = 0, cyc[6] = {0, 0, 0, 0, 0, 0}, tq = 0, st_lvl = 0, st_sgn = 0, st_nnc = 0;
 #define DOPF_TIC() tq = clock64()
 #define DOPF_TOC(i) { const unsigned long long t2_ = clock64(); cyc[i] += t2_ - tq; tq = t2_; }
 #else
@@ -1394,6 +1394,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
                 A0[c] = w * d0 - mc - theta; B0[c] = w * c0 - mc + theta;
             }
         }
+        if (rep == 0 && halt) return -1;         // (uniform; the loads above are on their way, nothing has been stored)
         // (D, C)(nu) of step c, d(C - D)/dnu; shift = Psi at the step's net injection minus its nu-independent anchor
         auto eval = [&](int c, double nu, double &dd, double &cc, double &s1) {
             if (!LINES) {
@@ -1724,6 +1725,20 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
 #pragma unroll
             for (int c = 0; c < NCH; ++c) chg = chg || nkind[c] != kind[c];
             const bool changed = group_bits<LPS>(chg, gbase) != 0ull;
+#ifdef DOPF_STATS
+            {   // why a round did not certify: levels outside the band (contacts to add) / price jumps of the wrong sign (to release) /
+                // Newton did not converge — per lane group and round
+                bool lv = false, sg = false;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) { lv = lv || (nkind[c] != 0 && kind[c] == 0); sg = sg || (nkind[c] == 0 && kind[c] != 0); }
+                const bool anyLv = group_bits<LPS>(lv, gbase) != 0ull, anySg = group_bits<LPS>(sg, gbase) != 0ull;
+                if (li == 0 && !gdone && !cert) {
+                    if (anyLv) ++st_lvl;
+                    if (anySg) ++st_sgn;
+                    if (!nconv) ++st_nnc;
+                }
+            }
+#endif
 
             // ---- D. accept, repair the contact set, or give up --------------------------------------------------
             DOPF_TOC(2)
@@ -1765,6 +1780,9 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
         __builtin_amdgcn_wave_barrier();
     }
 #ifdef DOPF_STATS
+    if (st_lvl) atomicAdd(&v.st->dbg_scans, st_lvl);               // (the scan body's counters, unused while it has nothing to do)
+    if (st_sgn) atomicAdd(&v.st->dbg_wave_loops, st_sgn);
+    if (st_nnc) atomicAdd(&v.st->dbg_events, st_nnc);
     if (st_rounds) atomicAdd(&v.st->dbg_reason[0], st_rounds);
     if (st_newton) atomicAdd(&v.st->dbg_reason[1], st_newton);
     if (lane == 0) for (int i = 0; i < 6; ++i) atomicAdd(&v.st->dbg_cyc[i], cyc[i]);
@@ -1814,7 +1832,10 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
         else v.part_scost_w[blk] = cw;
         v.item_fail[blk] = blockFail;
     }
-    __syncthreads();                                 // (callers rely on the body ending on a barrier)
+    // The scan body reads the sto_fail words other waves have just stored: that needs the full barrier (stores
+    // acknowledged). With nothing left over — the usual case — nobody reads anything of this block's again: its waves
+    // end without waiting for their rows to be acknowledged.
+    if (blockFail != 0) __syncthreads();
     { const int rep = 0, round = 0; DOPF_STAMP(6) }
     return blockFail;
 }
@@ -1853,9 +1874,9 @@ __global__ __launch_bounds__(256, 3) void k_sto(DevView v)
 {
     // (TAIL: the generator launch in front of this one has added its sums; the grid's last block is the tail block)
     if (TAIL && (int)blockIdx.x == v.nStoItems) { tail_block(v.self); return; }
-    if (v.st->halt) return;
-    const int left = sto_warm_body<LPS, NCH, LINES, TAIL>(v, blockIdx.x);   // ends on a __syncthreads: its sto_fail
-    sto_cold_body<LPS, NCH, LINES, TAIL>(v, blockIdx.x, left);               // flags are visible to the block here
+    const int left = sto_warm_body<LPS, NCH, LINES, TAIL>(v, blockIdx.x, v.st->halt);   // (with something left over it ends on a
+    if (left < 0) return;                                                                // __syncthreads: the sto_fail flags are visible)
+    sto_cold_body<LPS, NCH, LINES, TAIL>(v, blockIdx.x, left);
 }
 
 // All x-updates of one copper-plate iteration in ONE launch: blocks [0, nStoItems) solve storages (warm start,
@@ -1879,11 +1900,11 @@ __global__ __launch_bounds__(256, 3) void k_agents(DevView v)
         if (v.genBlocks > 0) gen_pair_stream<256, TAIL>(v, blockIdx.x - nS, v.genBlocks);
         else gen_pair_body<256, TAIL, true>(v, blockIdx.x - nS);
     } else {
-        if (v.st->halt) return;
         if ((int)blockIdx.x < nS) {
-            const int left = sto_warm_body<LPS, NCH, false, TAIL>(v, blockIdx.x);     // ends on a __syncthreads: its sto_fail
-            sto_cold_body<LPS, NCH, false, TAIL>(v, blockIdx.x, left);                // flags are visible to the block here
+            const int left = sto_warm_body<LPS, NCH, false, TAIL>(v, blockIdx.x, v.st->halt);   // (with something left over it ends on a
+            if (left >= 0) sto_cold_body<LPS, NCH, false, TAIL>(v, blockIdx.x, left);            // __syncthreads: the sto_fail flags are visible)
         } else {
+            if (v.st->halt) return;
             gen_pair_skip_body<256, TAIL>(v, blockIdx.x - nS);
         }
     }

@@ -651,9 +651,107 @@ __global__ __launch_bounds__(256) void k_xchg(DevView v, XchgView x)
     }
 }
 
+// The same sum for vectors of more than one chunk per rank (the 118-node / 186-line network: 659 kB, 41 chunks): as an
+// all-gather every rank would send and receive world x n doubles per iteration (5.3 MB at 8 ranks). Here chunk c has an OWNER,
+// rank c % world:
+//   1. every rank stores its copy of chunk c into the owner's receive area only and publishes its flag there;
+//   2. the owner's block waits for the world copies, adds them in RANK ORDER, stores the sum into every rank's sum
+//      region and publishes a sum flag there;
+//   3. every rank's block waits for the sum flag of its chunk and copies the sum into its consensus vector.
+// 2 n doubles out and 2 n in per rank and iteration, whatever the world size; every rank receives the owner's sum, so
+// the replicated state stays bitwise identical. A block sends before it waits, an owner waits only for sends, the
+// others only for the owner: no cycle, whatever the order blocks run in. Two parities suffice as before (a rank sends
+// k+2 only after it has consumed the sum of k+1, which exists only after everybody's k+1 has been consumed).
+__global__ __launch_bounds__(256) void k_xchg_rs(DevView v, XchgView x)
+{
+    if (v.st->halt) return;
+    __shared__ int bad;
+    const int tid = threadIdx.x, W = x.world, me = x.me, chunk = blockIdx.x, owner = chunk % W;
+    const unsigned long long seq = (unsigned long long)v.st->iters_total + 1ull;
+    const size_t par = (size_t)(seq & 1ull), n = x.n, j0 = (size_t)chunk * kXchgChunk;
+    constexpr int U = kXchgChunk / 256;
+    if (tid == 0) bad = 0;
+    {   // 1. this rank's copy -> the owner
+        double *dst = x.data[owner] + (par * W + me) * n;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t j = j0 + tid + 256 * (size_t)u;
+            if (j < n) dst[j] = v.cons[j];
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0)
+        __hip_atomic_store(x.flags[owner] + (par * W + me) * x.nchunks + chunk, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long t0 = wall_clock64();
+    if (me == owner) {
+        // 2. wait for the world copies, add them in rank order, hand the sum to everybody
+        if (tid < W) {
+            const unsigned long long *f = x.flags[me] + (par * W + tid) * x.nchunks + chunk;
+            bool ok = v.st->xchg_timeout == 0;
+            while (ok && __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+                __builtin_amdgcn_s_sleep(4);
+                if (wall_clock64() - t0 > x.timeout_ticks) ok = false;
+            }
+            if (!ok) atomicOr(&bad, 1);
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        if (!bad) {
+            const double *mine = x.data[me] + par * W * n;
+            double sum[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t j = j0 + tid + 256 * (size_t)u;
+                sum[u] = 0.0;
+                if (j < n) {
+                    sum[u] = mine[j];
+                    for (int r = 1; r < W; ++r) sum[u] += mine[(size_t)r * n + j];
+                }
+            }
+            for (int q = 0; q < W; ++q) {
+                const int r = (me + 1 + q) % W;                // the peers first, the own region last
+                double *dst = x.sum[r] + par * n;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const size_t j = j0 + tid + 256 * (size_t)u;
+                    if (j < n) dst[j] = sum[u];
+                }
+            }
+            __threadfence_system();
+            __syncthreads();
+            if (tid < W)
+                __hip_atomic_store(x.sflags[tid] + par * x.nchunks + chunk, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    // 3. the summed chunk (a lost peer: the owner publishes nothing, everybody's wait ends at the deadline)
+    if (tid == 0) {
+        const unsigned long long *f = x.sflags[me] + par * x.nchunks + chunk;
+        bool ok = v.st->xchg_timeout == 0 && !bad;
+        while (ok && __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > x.timeout_ticks) ok = false;
+        }
+        if (!ok) bad = 1;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (bad) {
+        if (tid == 0) v.st->xchg_timeout = 1;
+        return;
+    }
+    const double *res = x.sum[me] + par * n;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t j = j0 + tid + 256 * (size_t)u;
+        if (j < n) v.cons[j] = res[j];
+    }
+}
+
 void launch_xchg(const DevView &v, const XchgView &x, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_xchg, dim3(x.nchunks), dim3(256), 0, s, v, x);
+    if (x.rs) hipLaunchKernelGGL(k_xchg_rs, dim3(x.nchunks), dim3(256), 0, s, v, x);
+    else hipLaunchKernelGGL(k_xchg, dim3(x.nchunks), dim3(256), 0, s, v, x);
 }
 
 // ------------------------------------------------------------------------------------------------

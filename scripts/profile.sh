@@ -11,7 +11,7 @@ W=${1:-config2}
 MODE=${2:-default}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/prof_$W
-ARGS="bench.py --workload $W --no-cpu-baseline --no-also"      # bench.py defaults: 48 warm-up + 400 timed iterations
+ARGS="bench.py --workload $W --no-side"      # bench.py defaults: 48 warm-up + 400 timed iterations
 if [ "$MODE" = "driver" ]; then OUT=${OUT}_driver; ARGS="$ARGS --gpus 1 --steps 20 --warmup 5"; fi
 RAW=/tmp/dopf_prof_${W}_$MODE      # raw traces / counter dumps stay on the box (gpurun_out/ is copied back only below 64 MiB)
 rm -rf $RAW; mkdir -p $OUT $RAW

@@ -5,6 +5,7 @@ sys.path.insert(0, os.getcwd())
 import numpy as np, dopf_pkg
 pkg = dopf_pkg.load()
 from decentralopf_jl_amd import _capi, synth
+_capi._pin_hip_runtime()
 api = _capi.CApi("scripts/tmp/libdopf_stats.so", "dopf_")
 api.lib.dopf_debug_timeline.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32]
 idx = int(sys.argv[1]) if len(sys.argv) > 1 else 2

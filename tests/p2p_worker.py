@@ -66,6 +66,22 @@ assert pp.N * pp.T + 2 * pp.L * pp.T + 1 > 2048
 compare(pp, 3, (1, 5, 21), dict(eps=0.0, gamma=1.0 / A, w_flow=0.3 / A), 1e-8)
 print("chunks ok", flush=True)
 
+# the reduce-scatter + all-gather form of the exchange (every chunk has an owner that adds the ranks' copies and hands the
+# sum to everybody): forced on the cases above, and chosen by the library itself on a vector of more than one chunk per
+# shard (40 nodes, 60 lines, 48 steps: 7 681 doubles = 4 chunks, three shards)
+os.environ["DOPF_XCHG_REDUCE_SCATTER"] = "1"
+compare(pp, 3, (1, 5, 21), dict(eps=0.0, gamma=1.0 / A, w_flow=0.3 / A), 1e-8)
+kwn = dict(CASES["network"])
+ppn = synth.synthetic_case(kwn.pop("n_gen"), kwn.pop("n_sto"), kwn.pop("T"), **kwn)
+for n in (2, 3):
+    compare(ppn, n, (1, 4, 7), dict(eps=0.0, gamma=0.01), 1e-9)
+del os.environ["DOPF_XCHG_REDUCE_SCATTER"]
+pp4 = synth.synthetic_case(320, 40, 48, N=40, L=60, seed=43, fmax_factor=0.7, fmax_min=5)
+A4 = pp4.G + pp4.S
+assert (pp4.N * pp4.T + 2 * pp4.L * pp4.T + 1 + 2047) // 2048 > 3
+compare(pp4, 3, (1, 5, 15), dict(eps=0.0, gamma=1.0 / A4, w_flow=0.3 / A4), 1e-8)
+print("reduce-scatter ok", flush=True)
+
 # the reference's shipped case: stops like check_convergence! on both shards
 nodes, lines, gens, stos = network.three_node_case()
 pp3 = network.pack(nodes, gens, stos, lines)

@@ -98,3 +98,44 @@ def test_c_example_sharded_run_equals_the_reference_run(tmp_path, shards):
     assert "converged after 476 iterations, total cost 14034.51 (%d shards)" % shards in r.stdout
     assert "t=1 nodal prices -36.597 -15.216 -30.000" in r.stdout
     assert "t=2 nodal prices -81.976 -4.013 -30.000" in r.stdout
+
+
+def test_library_and_pytorch_share_one_rccl_and_one_hip_runtime_whatever_the_order():
+    """Round 2's abort inside dopf_create (gpurun_out/r2_bis*.log): the library had dlopen'ed the SYSTEM's RCCL because
+    PyTorch's copy was not mapped yet; PyTorch's arrived later. Now the library loads the RCCL that sits next to the HIP
+    runtime the process runs on, the Python loader pins PyTorch's runtime before libdopf_hip.so when PyTorch is installed,
+    and a second copy is refused (DOPF_E_UNSUPPORTED) instead of used. Child process: load the library, make it load
+    RCCL, THEN import torch — one librccl, one libamdhip64 mapped, clean exit."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_order_worker.py")
+    r = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl order worker: ok" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_a_second_rccl_in_the_process_is_refused_not_used():
+    """Force the hazard: the system's librccl is loaded by hand next to the one the library picked. The next call that
+    needs RCCL returns DOPF_E_UNSUPPORTED and names both copies."""
+    import subprocess
+    import sys
+    sys_rccl = "/opt/rocm/lib/librccl.so.1"
+    if not os.path.exists(sys_rccl):
+        pytest.skip("no system RCCL to collide with")
+    code = (
+        "import os, sys, ctypes as C\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "import dopf_pkg; dopf_pkg.load()\n"
+        "from decentralopf_jl_amd import _capi\n"
+        "api = _capi.hip_api()\n"
+        "buf = (C.c_char * _capi.COMM_ID_BYTES)()\n"
+        "assert api.comm_unique_id(buf) == 0\n"
+        "maps = open('/proc/self/maps').read()\n"
+        f"if {sys_rccl!r} in maps or os.path.realpath({sys_rccl!r}) in maps: print('system copy in use: nothing to collide'); sys.exit(0)\n"
+        f"C.CDLL({sys_rccl!r}, mode=C.RTLD_LOCAL)\n"
+        "rc = api.comm_unique_id(buf)\n"
+        "msg = api.last_error(None).decode()\n"
+        "print(rc, msg)\n"
+        "assert rc == -4 and 'two copies of RCCL' in msg, (rc, msg)\n"
+        "print('refused')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and ("refused" in r.stdout or "nothing to collide" in r.stdout), (r.returncode, r.stdout[-1500:], r.stderr[-1500:])

@@ -198,17 +198,20 @@ def test_peer_exchange_shards_on_one_device(hip_api):
     r = subprocess.run([sys.executable, worker], env=dict(os.environ, GPU_MAX_HW_QUEUES="8", DOPF_XCHG_TIMEOUT_MS="4000"),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "p2p worker: ok" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
-    for line in ("equal network 2", "equal network 3", "equal copper plate 3", "equal copper plate T96 2", "chunks ok", "stop ok", "missing peer ok"):
+    for line in ("equal network 2", "equal network 3", "equal copper plate 3", "equal copper plate T96 2", "chunks ok", "reduce-scatter ok", "stop ok", "missing peer ok"):
         assert line in r.stdout, (line, r.stdout[-1500:])
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_ranks_in_separate_processes_peer_exchange(hip_api, tmp_path, world):
+@pytest.mark.parametrize("world,form", [(2, "all-gather"), (3, "all-gather"), (3, "reduce-scatter")])
+def test_ranks_in_separate_processes_peer_exchange(hip_api, tmp_path, world, form):
     """One process per rank, receive areas shared through hipIpc handles — the form a launcher-started multi-GPU run
-    uses. With fewer GPUs than ranks the ranks share device 0 (the exchange does not care where a peer's memory lives)."""
+    uses. With fewer GPUs than ranks the ranks share device 0 (the exchange does not care where a peer's memory lives).
+    reduce-scatter: the owner form of the exchange (k_xchg_rs), forced on this one-chunk vector."""
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rank_worker.py")
     idf = str(tmp_path / "handle")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DOPF_XCHG_TIMEOUT_MS="20000")
+    if form == "reduce-scatter":
+        env["DOPF_XCHG_REDUCE_SCATTER"] = "1"
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), idf, str(tmp_path / f"out{r}.npz"), "25", "xchg"], env=env)
              for r in range(world)]
     try:
