@@ -137,7 +137,8 @@ class CApi:
             self._sig("get_agent_penalty", C.c_int, [ctxp, C.c_int32, c_double_p, c_double_p])
             self._sig("get_residual_vectors", C.c_int, [ctxp, c_double_p, c_double_p, c_double_p])
             self._sig("central_solve", C.c_int, [C.POINTER(DopfProblem), C.POINTER(DopfParams), C.c_double, C.c_int32,
-                                                 C.POINTER(DopfCentralResult)] + [c_double_p] * 7)
+                                                 C.POINTER(DopfCentralResult)] + [c_double_p] * 9)
+            self._sig("get_node_results", C.c_int, [ctxp, c_double_p, c_double_p, c_double_p])
             # consensus sum across GPUs inside the library (RCCL, loaded on first use)
             self._sig("comm_unique_id", C.c_int, [C.c_void_p])
             self._sig("comm_init", C.c_int, [ctxp, C.c_int32, C.c_int32, C.c_void_p])
@@ -293,6 +294,12 @@ class Engine:
         it, conv = C.c_int32(0), C.c_int32(0)
         self._chk(self.api.sync(self._ctx, C.byref(it), C.byref(conv)))
         return it.value, bool(conv.value)
+
+    def get_node_results(self):
+        """ResultNode.{generation, discharge, charge} of the last result, each (N, T) (src/structures/results.jl:19-35)."""
+        outs = [np.zeros(self.N * self.T) for _ in range(3)]
+        self._chk(self.api.get_node_results(self._ctx, *[_dp(o) for o in outs]))
+        return tuple(o.reshape(self.T, self.N).T.copy() for o in outs)
 
     def solver_failures(self) -> int:
         return int(self.api.solver_failures(self._ctx))
@@ -526,12 +533,14 @@ def central_solve(api: CApi, *, N, L, T, demand, ptdf, f_max, gen_mc, gen_pmax, 
     res = DopfCentralResult()
     P, D, Cc, E = np.zeros(G * T), np.zeros(S * T), np.zeros(S * T), np.zeros(S * T)
     lam, nodal, flow = np.zeros(T), np.zeros(N * T), np.zeros(L * T)
+    fu, fl = np.zeros(L * T), np.zeros(L * T)
     rc = api.central_solve(C.byref(prob), C.byref(q), float(tol), int(max_iters), C.byref(res), _dp(P), _dp(D), _dp(Cc), _dp(E),
-                           _dp(lam), _dp(nodal), _dp(flow))
+                           _dp(lam), _dp(nodal), _dp(flow), _dp(fu), _dp(fl))
     if rc != 0:
         msg = api.last_error(None)
         raise DopfError(f"dopf_central_solve failed ({rc}): {msg.decode() if msg else ''}")
     return dict(objective=res.objective, dual_objective=res.dual_objective, primal_infeasibility=res.primal_infeasibility,
                 gap=res.gap, iterations=res.iterations, converged=bool(res.converged),
                 P=P.reshape(G, T), D=D.reshape(S, T), C=Cc.reshape(S, T), E=E.reshape(S, T), system_price=lam,
-                nodal_price=nodal.reshape(T, N).T.copy(), line_utilization=flow.reshape(T, L).T.copy())
+                nodal_price=nodal.reshape(T, N).T.copy(), line_utilization=flow.reshape(T, L).T.copy(),
+                flow_upper_dual=fu.reshape(T, L).T.copy(), flow_lower_dual=fl.reshape(T, L).T.copy())

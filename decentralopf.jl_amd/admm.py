@@ -59,6 +59,15 @@ class ResultStorage:
 
 
 @dataclass
+class ResultNode:
+    """src/structures/results.jl:19-35: what the units of one node produce, discharge and charge per timestep."""
+    node: Node
+    generation: np.ndarray
+    discharge: np.ndarray
+    charge: np.ndarray
+
+
+@dataclass
 class Result:
     unit_to_result: Dict[int, object]
     generation: np.ndarray
@@ -69,9 +78,13 @@ class Result:
     total_costs: float
     injection: np.ndarray
     line_utilization: np.ndarray
+    node_to_result: Dict[int, ResultNode] = field(default_factory=dict)
 
     def of(self, unit):
         return self.unit_to_result[id(unit)]
+
+    def of_node(self, node):
+        return self.node_to_result[id(node)]
 
 
 @dataclass
@@ -144,8 +157,16 @@ class ADMM:
             q0 = (prev.of(s).discharge - prev.of(s).charge) if prev else 0.0
             u2r[id(s)] = ResultStorage(s, D[i].copy(), C[i].copy(), E[i].copy(), **extras(G + i, (D[i] - C[i]) - q0))
         T = self.packed.T
+        if hasattr(self.engine.api, "get_node_results"):        # dopf_get_node_results (the device adds the units of a node)
+            ng, nd, nc = self.engine.get_node_results()
+        else:                                                   # a backend without it: the same sums here
+            ng, nd, nc = (np.zeros((self.packed.N, T)) for _ in range(3))
+            np.add.at(ng, np.asarray(self.packed.gen_node, dtype=np.int64), P)
+            np.add.at(nd, np.asarray(self.packed.sto_node, dtype=np.int64), D)
+            np.add.at(nc, np.asarray(self.packed.sto_node, dtype=np.int64), C)
+        n2r = {id(n): ResultNode(n, ng[i].copy(), nd[i].copy(), nc[i].copy()) for i, n in enumerate(self.nodes)}
         return Result(u2r, P.sum(axis=0) if P.size else np.zeros(T), D.sum(axis=0) if D.size else np.zeros(T),
-                      C.sum(axis=0) if C.size else np.zeros(T), aU, aK, cost, inj, flow)
+                      C.sum(axis=0) if C.size else np.zeros(T), aU, aK, cost, inj, flow, n2r)
 
     def _after(self, done: int):
         lam_res, mu_res, rho_res, it = self.engine.get_residuals()

@@ -130,8 +130,7 @@ def central_reference(nodes: Sequence[Node], generators: Sequence[Generator], st
 def central_reference_on_device(nodes: Sequence[Node], generators: Sequence[Generator], storages: Sequence[Storage],
                                 lines: Sequence[Line], *, tol: float = 1e-9, max_iters: int = 200000, device: int = -1) -> CentralResult:
     """The same LP solved on the GPU by libdopf_hip (dopf_central_solve: first-order primal-dual method, csrc/kernels_central.hip)
-    — for cases beyond a host LP solver, and as a cross-check that shares no code with HiGHS. The two flow duals are not
-    returned separately (the nodal price is formed from them on the library side, with the reference's formula)."""
+    — for cases beyond a host LP solver, and as a cross-check that shares no code with HiGHS."""
     from . import _capi
     pp = pack(nodes, generators, storages, lines)
     r = _capi.central_solve(_capi.hip_api(), tol=tol, max_iters=max_iters, params=_capi.default_params(device=device),
@@ -141,7 +140,6 @@ def central_reference_on_device(nodes: Sequence[Node], generators: Sequence[Gene
     inj = -np.asarray(pp.demand, dtype=np.float64).copy()
     np.add.at(inj, pp.gen_node, r["P"])
     np.add.at(inj, pp.sto_node, r["D"] - r["C"])
-    nan = np.full((pp.L, pp.T), np.nan)
     return CentralResult(objective=r["objective"], generation=r["P"], discharge=r["D"], charge=r["C"], level=r["E"], injection=inj,
-                         line_utilization=r["line_utilization"], system_price=r["system_price"], flow_upper_dual=nan,
-                         flow_lower_dual=nan.copy(), nodal_price=r["nodal_price"])
+                         line_utilization=r["line_utilization"], system_price=r["system_price"], flow_upper_dual=r["flow_upper_dual"],
+                         flow_lower_dual=r["flow_lower_dual"], nodal_price=r["nodal_price"])

@@ -799,6 +799,24 @@ int dopf_get_nodal_price(dopf_ctx *c, int32_t which, double *out)
     return DOPF_OK;
 }
 
+int dopf_get_node_results(dopf_ctx *c, double *generation, double *discharge, double *charge)
+{
+    if (!c) return DOPF_E_INVALID;
+    DeviceGuard guard(c->device);
+    const size_t NT = (size_t)c->v.N * c->v.T;
+    double *tmp = nullptr;
+    HIPCHK(c, hipMalloc((void **)&tmp, 3 * NT * sizeof(double)));
+    launch_node_results(c->v, tmp, tmp + NT, tmp + 2 * NT, c->main);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->main);
+    double *outs[3] = {generation, discharge, charge};
+    for (int k = 0; k < 3 && e == hipSuccess; ++k)
+        if (outs[k]) e = hipMemcpy(outs[k], tmp + k * NT, NT * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(tmp);
+    if (e != hipSuccess) return fail(c, DOPF_E_DEVICE, "dopf_get_node_results: %s", hipGetErrorString(e));
+    return DOPF_OK;
+}
+
 int dopf_set_state(dopf_ctx *c, const double *P, const double *D, const double *C, const double *avg_U,
                    const double *avg_K, const double *lambda, const double *mu, const double *rho, int32_t iteration)
 {

@@ -38,7 +38,8 @@ struct Metrics {
 
 extern "C" int dopf_central_solve(const dopf_problem *p, const dopf_params *q, double tol, int32_t max_iters,
                                   dopf_central_result *res, double *P, double *D, double *C, double *E,
-                                  double *system_price, double *nodal_price, double *line_utilization)
+                                  double *system_price, double *nodal_price, double *line_utilization,
+                                  double *flow_upper_dual, double *flow_lower_dual)
 {
     if (!p || !q || !res || !(tol > 0) || max_iters < 1) return fail(nullptr, DOPF_E_INVALID, "bad argument");
     memset(res, 0, sizeof *res);
@@ -166,5 +167,11 @@ extern "C" int dopf_central_solve(const dopf_problem *p, const dopf_params *q, d
             }
     }
     if (line_utilization && LT) HIPCHK(c, hipMemcpy(line_utilization, v.flow, sizeof(double) * LT, hipMemcpyDeviceToHost));
+    // dual.(FlowUpper), dual.(FlowLower) (:71): the multiplier of |flow| <= max_capacity is positive where the upper limit
+    // binds and negative where the lower one does; either dual is d objective / d max_capacity <= 0
+    for (size_t i = 0; i < LT; ++i) {
+        if (flow_upper_dual) flow_upper_dual[i] = -std::max(yf[i], 0.0);
+        if (flow_lower_dual) flow_lower_dual[i] = -std::max(-yf[i], 0.0);
+    }
     return DOPF_OK;
 }

@@ -216,6 +216,7 @@ struct XchgView {
 void launch_xchg(const DevView &v, const XchgView &x, hipStream_t s);   // cons <- sum over ranks of cons (rank order)
 void launch_dual(const DevView &v, hipStream_t s, const XchgView *xd = nullptr);   // xd: peer exchange inside the one-block kernel
 //      // consensus -> duals, residuals, prices, status
-void launch_derive(const DevView &v, hipStream_t s, bool from_primal);   // consensus -> inj/s/flow/price (no dual step)
+void launch_derive(const DevView &v, hipStream_t s, bool from_primal);
+void launch_node_results(const DevView &v, double *gen, double *dis, double *chg, hipStream_t s);   // [n + N*t] each, device pointers   // consensus -> inj/s/flow/price (no dual step)
 
 }  // namespace dopf

@@ -1488,6 +1488,33 @@ __global__ __launch_bounds__(256) void k_derive_level(DevView v)
     }
 }
 
+// ResultNode.{generation, discharge, charge} (results.jl:19-35): per node and timestep the sums over the node's units,
+// on request. Block = (node, chunk of 32 timesteps), 8 agent lanes per timestep, fixed-order sums.
+__global__ __launch_bounds__(256) void k_node_results(DevView v, double *gen, double *dis, double *chg)
+{
+    __shared__ double red[3][256];
+    const int N = v.N, T = v.T, TC = (T + 31) / 32;
+    const int n = blockIdx.x / TC, t = (blockIdx.x % TC) * 32 + (threadIdx.x & 31), r = threadIdx.x >> 5;
+    double g = 0.0, d = 0.0, c = 0.0;
+    if (t < T) {
+        for (int a = v.node_gen_beg[n] + r; a < v.node_gen_beg[n + 1]; a += 8) g += v.P[(size_t)a * T + t];
+        for (int a = v.node_sto_beg[n] + r; a < v.node_sto_beg[n + 1]; a += 8) { d += v.D[(size_t)a * T + t]; c += v.C[(size_t)a * T + t]; }
+    }
+    red[0][threadIdx.x] = g; red[1][threadIdx.x] = d; red[2][threadIdx.x] = c;
+    __syncthreads();
+    if (r == 0 && t < T) {
+        double sg = 0.0, sd = 0.0, sc = 0.0;
+        for (int q = 0; q < 8; ++q) { sg += red[0][q * 32 + threadIdx.x]; sd += red[1][q * 32 + threadIdx.x]; sc += red[2][q * 32 + threadIdx.x]; }
+        const size_t i = (size_t)n + (size_t)N * t;
+        gen[i] = sg; dis[i] = sd; chg[i] = sc;
+    }
+}
+
+void launch_node_results(const DevView &v, double *gen, double *dis, double *chg, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_node_results, dim3(v.N * ((v.T + 31) / 32)), dim3(256), 0, s, v, gen, dis, chg);
+}
+
 void launch_derive(const DevView &v, hipStream_t s, bool from_primal)
 {
     const size_t NT = (size_t)v.N * v.T, LT = (size_t)v.L * v.T;

@@ -222,8 +222,12 @@ function dopf_result(admm::ADMM)
                      (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cdouble}),
                      admm.ctx, inj, aU, aK, fl, cost), admm.ctx)
     P, D, C, E = dopf_primal(admm)
+    # ResultNode.{generation, discharge, charge} (src/structures/results.jl:19-35): N x T, row n = admm.nodes[n]
+    ng = zeros(N, T); nd = zeros(N, T); nc = zeros(N, T)
+    dopf_check(ccall((:dopf_get_node_results, DOPF_LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                     admm.ctx, ng, nd, nc), admm.ctx)
     return (generation=P, discharge=D, charge=C, level=E, injection=inj, avg_U=aU, avg_K=aK,
-            line_utilization=fl, total_costs=cost[])
+            line_utilization=fl, total_costs=cost[], node_generation=ng, node_discharge=nd, node_charge=nc)
 end
 
 # after a batch of iterations: iteration counter, stop flags, the dual sets get_nodal_price needs
@@ -301,6 +305,48 @@ function get_nodal_price(iteration::Int)
     return nodal_price
 end
 
+"""
+    export_results(admm, filename; parent_dir = "results/")
+
+The reference's export (src/helpers/output.jl:1-85): `<filename>_duals.csv` (iteration,dual,timestep,line,value; duals
+lambda, rho, mue in that order; `line` empty for lambda; row i = the dual USED in iteration i), `<filename>_generators.csv`
+(iteration,generator,timestep,generation) and `<filename>_storages.csv` (iteration,storage,timestep,charge,discharge), one
+row per iteration 1..admm.iteration, written as plain text (no CSV.jl / DataFrames needed). Needs the iteration history:
+`ADMM(...; record = true)` — which is also what any reference-style script that reads `admm.results[end]` needs.
+"""
+function export_results(admm::ADMM, filename::String; parent_dir::String="results/")
+    admm.record || error("export_results needs the iteration history: create ADMM(...; record = true)")
+    mkpath(parent_dir)
+    n_it = min(admm.iteration, length(admm.results))
+    open(joinpath(parent_dir, filename * "_duals.csv"), "w") do f
+        println(f, "iteration,dual,timestep,line,value")
+        for (name, hist) in (("lambda", admm.lambdas), ("rho", admm.rhos), ("mue", admm.mues))
+            for i in 1:n_it, t in admm.T
+                if name == "lambda"
+                    println(f, i, ",lambda,", t, ",,", hist[i][t])
+                else
+                    for l in admm.L
+                        println(f, i, ",", name, ",", t, ",", l, ",", hist[i][l, t])
+                    end
+                end
+            end
+        end
+    end
+    open(joinpath(parent_dir, filename * "_generators.csv"), "w") do f
+        println(f, "iteration,generator,timestep,generation")
+        for (g, gen) in enumerate(admm.generators), i in 1:n_it, t in admm.T
+            println(f, i, ",", gen.name, ",", t, ",", admm.results[i].generation[t, g])
+        end
+    end
+    open(joinpath(parent_dir, filename * "_storages.csv"), "w") do f
+        println(f, "iteration,storage,timestep,charge,discharge")
+        for (s, sto) in enumerate(admm.storages), i in 1:n_it, t in admm.T
+            println(f, i, ",", sto.name, ",", t, ",", admm.results[i].charge[t, s], ",", admm.results[i].discharge[t, s])
+        end
+    end
+    return nothing
+end
+
 struct CCentralResult          # == struct dopf_central_result (include/dopf.h)
     objective::Cdouble
     dual_objective::Cdouble
@@ -334,6 +380,7 @@ function central_reference(nodes::Vector{Node}, generators::Vector{Generator}, s
     sto_node = Cint[node_to_id[s.node] - 1 for s in storages]
     P = zeros(T, G); D = zeros(T, S); C = zeros(T, S); E = zeros(T, S)
     lambda = zeros(T); nodal = zeros(N, T); util = zeros(L, T)
+    flow_upper = zeros(L, T); flow_lower = zeros(L, T)          # dual.(FlowUpper), dual.(FlowLower), opf_central_reference.jl:71
     res = Ref(CCentralResult(0.0, 0.0, 0.0, 0.0, 0, 0))
     GC.@preserve demand ptdf f_max gen_mc gen_pmax gen_node sto_mc sto_pmax sto_emax sto_node begin
         prob = Ref(CProblem(N, L, T, G, S, pointer(demand), pointer(ptdf), pointer(f_max), pointer(gen_mc),
@@ -342,11 +389,12 @@ function central_reference(nodes::Vector{Node}, generators::Vector{Generator}, s
         par = Ref(CParams(0.3, 10.0, 1.0, 1e-3, 1e-2, 0, 0, device, 0, C_NULL))
         rc = ccall((:dopf_central_solve, DOPF_LIB), Cint,
                    (Ref{CProblem}, Ref{CParams}, Cdouble, Cint, Ref{CCentralResult}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble},
-                    Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
-                   prob, par, tol, max_iters, res, P, D, C, E, lambda, nodal, util)
+                    Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                   prob, par, tol, max_iters, res, P, D, C, E, lambda, nodal, util, flow_upper, flow_lower)
         dopf_check(rc, Ptr{Cvoid}(C_NULL))
     end
     res[].converged == 0 && error("central LP: gap $(res[].gap) after $(res[].iterations) iterations")
     return (objective=res[].objective, generation=permutedims(P), discharge=permutedims(D), charge=permutedims(C),
-            level=permutedims(E), line_utilization=util, system_price=lambda, nodal_price=nodal)
+            level=permutedims(E), line_utilization=util, system_price=lambda, nodal_price=nodal,
+            flow_upper_dual=flow_upper, flow_lower_dual=flow_lower)
 end

@@ -183,6 +183,13 @@ int dopf_get_agent_penalty(dopf_ctx *ctx, int32_t agent, const double *delta, do
 /* which = 0: duals used by the last solve (what the reference's driver script evaluates),
  * which = 1: duals after the last update. out is N x T, [n + N*t]. */
 int dopf_get_nodal_price(dopf_ctx *ctx, int32_t which, double *out);
+
+/* ResultNode.{generation, discharge, charge} of the last result (src/structures/results.jl:19-35, filled by `update`,
+ * src/helpers/network_elements.jl:1-14, in the agent loop of Result(...), results.jl:72-106): per node and timestep the
+ * sums of its generators' output and of its storages' discharge and charge, layout [n + N*t] like the injection (which
+ * is generation + discharge - charge - demand). Any pointer may be NULL. Result.{generation, discharge, charge}
+ * (results.jl:37-47) are these summed over the nodes. Computed on request from the primal arrays (not on the hot path). */
+int dopf_get_node_results(dopf_ctx *ctx, double *generation /*N*T*/, double *discharge /*N*T*/, double *charge /*N*T*/);
 /* Any of P, D, C, avg_U, avg_K, lambda, mu, rho may be NULL (= keep). iteration >= 1 is the
  * value admm.iteration would have before the next solve; iteration == 1 means "no result yet"
  * only if all primal pointers are NULL and the state is untouched. */
@@ -216,14 +223,17 @@ int64_t dopf_solver_failures(dopf_ctx *ctx);
  * It is the parity target of the decentral run and independent of it. p holds ALL agents; q supplies device and flags.
  * Stops when |primal - dual objective| / (1 + |primal|) + worst violation / (1 + max demand) <= tol, or at max_iters.
  * Outputs (any may be NULL), layouts as in dopf_get_primal / dopf_get_consensus: P, D, C, E; system_price[T] = dual.(EB);
- * nodal_price[N*T] = lambda + sum_l (dual FlowUpper + dual FlowLower)[l,t] ptdf[l,:]; line_utilization[L*T] = ptdf * I. */
+ * nodal_price[N*T] = lambda + sum_l (dual FlowUpper + dual FlowLower)[l,t] ptdf[l,:]; line_utilization[L*T] = ptdf * I;
+ * flow_upper_dual[L*T] = dual.(FlowUpper), flow_lower_dual[L*T] = dual.(FlowLower) (opf_central_reference.jl:71-79: both are
+ * d objective / d max_capacity <= 0, non-zero only where that limit binds). */
 typedef struct dopf_central_result {
     double objective, dual_objective, primal_infeasibility, gap;
     int32_t iterations, converged;
 } dopf_central_result;
 int dopf_central_solve(const dopf_problem *p, const dopf_params *q, double tol, int32_t max_iters,
                        dopf_central_result *res, double *P, double *D, double *C, double *E,
-                       double *system_price, double *nodal_price, double *line_utilization);
+                       double *system_price, double *nodal_price, double *line_utilization,
+                       double *flow_upper_dual, double *flow_lower_dual);
 
 /* ---- consensus sum across GPUs inside the library (RCCL over xGMI, loaded at run time) -------------
  * Replaces nothing in the reference (it has no parallelism); what is distributed is the agent loop of

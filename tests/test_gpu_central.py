@@ -21,6 +21,18 @@ def test_three_node_case_matches_the_thesis_tables(hip_api, three_node, thesis):
     assert np.abs(r["line_utilization"] - np.asarray(c["flows"])).max() < 1e-4
     assert np.abs(r["system_price"] - np.asarray(c["lambda"])).max() < 1e-3
     assert np.abs(r["nodal_price"] - np.asarray(c["nodal_price"])).max() < 0.051         # the thesis prints one decimal
+    # dual.(FlowUpper), dual.(FlowLower) separately (opf_central_reference.jl:71): both <= 0, never both non-zero, non-zero only on
+    # a line at its limit, and the reference's nodal-price formula rebuilt from them gives what the library returned; against
+    # the host LP (HiGHS) where it returns the same vertex of the dual
+    fu, fl = r["flow_upper_dual"], r["flow_lower_dual"]
+    assert fu.shape == fl.shape == (pp.L, pp.T) and fu.max() <= 0 and fl.max() <= 0 and np.abs(fu * fl).max() == 0
+    util = np.abs(r["line_utilization"]) / np.asarray(pp.f_max)[:, None]
+    assert np.all((np.abs(fu) + np.abs(fl) < 1e-6) | (util > 1 - 1e-5))
+    assert (fu < -1e-3).any()                                                            # the case is congested
+    ptdf = np.asarray(pp.ptdf).reshape(pp.L, pp.N)
+    assert np.abs(r["system_price"][None, :] + ptdf.T @ (fu + fl) - r["nodal_price"]).max() < 1e-9
+    host = solve_central_packed(pp)
+    assert np.abs(fu + fl - (host.flow_upper_dual + host.flow_lower_dual)).max() < 2e-3
 
 
 @pytest.mark.parametrize("name", ["config1", "copper T96", "network 6x9", "network 118x186"])

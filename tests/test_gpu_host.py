@@ -153,3 +153,32 @@ def test_bench_line_keeps_the_driver_contract(tmp_path):
         assert k in ro, k
     assert ro["bound"] == "hbm" and ro["peak"] == 8000.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
     assert abs(d["value"] - d["config"]["agents_per_gpu"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_node_results_are_the_sums_over_the_units_of_each_node(hip_api, three_node):
+    """dopf_get_node_results = ResultNode.{generation, discharge, charge} (src/structures/results.jl:19-35, filled by `update`
+    in the agent loop of Result(...)): on the shipped case and on a seeded network with empty nodes, against numpy sums of
+    the primal arrays; injection = generation + discharge - charge - demand; the host's Result carries them per node."""
+    from helpers import make_engine
+    for pp, kw in ((three_node[4], dict()),
+                   (synth.synthetic_case(25, 6, 8, N=30, L=50, seed=17, fmax_factor=0.6, fmax_min=5), dict(gamma=0.05)),
+                   (synth.synthetic_case(3000, 300, 24, seed=31), dict(gamma=1.0 / 3300))):
+        e = make_engine(hip_api, pp, eps=0.0, **kw)
+        e.iterate(30)
+        P, D, C, _E = e.get_primal()
+        g, d, c = e.get_node_results()
+        want = [np.zeros((pp.N, pp.T)) for _ in range(3)]
+        np.add.at(want[0], np.asarray(pp.gen_node, dtype=np.int64), P)
+        np.add.at(want[1], np.asarray(pp.sto_node, dtype=np.int64), D)
+        np.add.at(want[2], np.asarray(pp.sto_node, dtype=np.int64), C)
+        for a, b in zip((g, d, c), want):
+            assert a.shape == (pp.N, pp.T) and np.abs(a - b).max() <= 1e-9 * (1.0 + np.abs(b).max())
+        inj = e.get_consensus()[0]
+        assert np.abs(g + d - c - np.asarray(pp.demand).reshape(pp.N, pp.T) - inj).max() <= 1e-8 * (1.0 + np.abs(inj).max())
+    nodes, lines, gens, stos = three_node[:4]
+    admm = pkg.ADMM(0.3, nodes, gens, stos, lines)
+    pkg.calculate_iteration(admm)
+    r = admm.results[-1]
+    assert np.allclose(sum(r.of_node(n).generation for n in nodes), r.generation)
+    assert np.allclose(r.of_node(stos[0].node).discharge, r.of(stos[0]).discharge)

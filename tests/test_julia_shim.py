@@ -77,6 +77,73 @@ def test_every_ccall_matches_a_header_prototype():
         assert need in used, need
 
 
+def header_arg_types():
+    """name -> list of C argument types (parameter names and const stripped, '*' attached)"""
+    text = re.sub(r"/\*.*?\*/", "", HDR, flags=re.S)
+    out = {}
+    for m in re.finditer(r"^\s*(?:const\s+)?[\w]+\s*\**\s*(dopf_\w+)\s*\(([^;{]*?)\)\s*;", text, re.M):
+        name, args = m.group(1), " ".join(m.group(2).split())
+        types = []
+        if args not in ("", "void"):
+            for a in args.split(","):
+                a = a.strip().replace("const ", "")
+                mm = re.match(r"([\w]+)\s*(\**)\s*\w*$", a)
+                assert mm, (name, a)
+                types.append(mm.group(1) + mm.group(2))
+        out[name] = types
+    return out
+
+
+# what a ccall may declare for a C argument type (Ref{T} = a scalar passed by reference, Ptr{T} = an array)
+ARG = {
+    "int32_t": {"Cint"}, "double": {"Cdouble"}, "int64_t": {"Clonglong"},
+    "double*": {"Ptr{Cdouble}", "Ref{Cdouble}"}, "int32_t*": {"Ptr{Cint}", "Ref{Cint}"},
+    "void*": {"Ptr{Cvoid}"}, "uint64_t*": {"Ptr{UInt64}"},
+    "dopf_ctx*": {"Ptr{Cvoid}"}, "dopf_multi*": {"Ptr{Cvoid}"},
+    "dopf_ctx**": {"Ref{Ptr{Cvoid}}"}, "dopf_multi**": {"Ref{Ptr{Cvoid}}"},
+    "dopf_problem*": {"Ref{CProblem}"}, "dopf_params*": {"Ref{CParams}"}, "dopf_central_result*": {"Ref{CCentralResult}"},
+}
+
+
+def split_top(s):
+    """split a Julia type tuple at top-level commas (Ref{Ptr{Cvoid}} holds braces)"""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch == "{":
+            depth += 1
+        elif ch == "}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def test_every_ccall_argument_type_matches_the_header():
+    """Not only the arity: every argument of every ccall is declared with a Julia type that has the C parameter's size and
+    meaning (Cint for int32_t, Ptr/Ref{Cdouble} for double *, Ref{CProblem} for const dopf_problem *, ...)."""
+    want = header_arg_types()
+    calls = re.findall(r"ccall\(\(:(\w+), DOPF_LIB\),\s*[\w{}]+,\s*\(((?:[^()]|\([^()]*\))*?)\)\s*,", CODE, re.S)
+    assert len(calls) >= 12
+    for sym, args in calls:
+        got = split_top(" ".join(args.split()))
+        assert len(got) == len(want[sym]), (sym, got, want[sym])
+        for i, (g, w) in enumerate(zip(got, want[sym])):
+            assert g in ARG[w], f"{sym}: argument {i + 1} is {w} in include/dopf.h, the ccall says {g}"
+    assert "dopf_get_node_results" in {c[0] for c in calls} and "dopf_central_solve" in {c[0] for c in calls}
+
+
+def test_export_results_is_there_and_needs_the_history():
+    assert re.search(r"function export_results\(admm::ADMM, filename::String", CODE)
+    assert "iteration,dual,timestep,line,value" in CODE and "iteration,generator,timestep,generation" in CODE
+    assert "iteration,storage,timestep,charge,discharge" in CODE
+    assert re.search(r"admm\.record \|\| error", CODE)
+
+
 def test_central_result_mirror_matches_the_header():
     body = re.search(r"typedef struct dopf_central_result \{(.*?)\} dopf_central_result;", HDR, re.S).group(1)
     want = []
