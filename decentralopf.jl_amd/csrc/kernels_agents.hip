@@ -719,9 +719,10 @@ __device__ __forceinline__ void box2(double a, double b, double ia, double idet,
 {
     const double Df = clampd((a * rD + b * rC) * idet, 0.0, pm);
     const double Cf = (rC + b * Df) * ia;
-    const double Dlo = clampd(rD * ia, 0.0, pm), Dhi = clampd((rD + b * pm) * ia, 0.0, pm);
     C = clampd(Cf, 0.0, pm);
-    D = Cf < 0.0 ? Dlo : (Cf > pm ? Dhi : Df);
+    // D given that C: with C on a bound the 1-D problem's clamp (rD/a resp. (rD + b pm)/a); with Cf inside the box it is Df
+    // again — interior: a^2 D = a rD + b rC + b^2 Df = a^2 Df; Df on a bound: the unclamped value lies beyond the same bound
+    D = clampd((rD + b * C) * ia, 0.0, pm);
     const bool fD = D > 0.0 && D < pm, fC = C > 0.0 && C < pm;
     sg = (fD && fC) ? s2 : ((fD || fC) ? ia : 0.0);
 }
@@ -821,7 +822,9 @@ struct StoAgent {
 };
 
 // `item_fail`: number of storages of this item the warm start left over (block-uniform); < 0 = read it
-template <int LPS, int NCH, bool LINES, bool TAIL = false>
+// FULLT: the horizon fills the lane group exactly (T == LPS * NCH: 24 = 8 x 3, 48 = 16 x 3, 96 = 32 x 3): T is then a
+// compile-time constant and every "is this step inside the horizon" test folds away
+template <int LPS, int NCH, bool LINES, bool TAIL = false, bool FULLT = false>
 __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, int item_fail)
 {
     constexpr int NG = 256 / LPS;
@@ -830,7 +833,7 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
     const int tid = threadIdx.x, lane = tid & 63, li = tid & (LPS - 1), grp = tid / LPS;
     const int gbase = lane & ~(LPS - 1);
     const Item it = v.sto_items[blk];
-    const int T = v.T, N = v.N;
+    const int T = FULLT ? LPS * NCH : v.T, N = v.N;
     if (item_fail < 0) item_fail = v.item_fail[blk];
     if (v.use_warm && item_fail == 0) {      // the warm start solved this whole item
         if (TAIL) return;                    // (nothing to add)
@@ -1298,7 +1301,7 @@ __device__ __forceinline__ int next_lane_i(int x)
 }
 
 // returns the number of storages of the item left to the scan (block-uniform)
-template <int LPS, int NCH, bool LINES, bool TAIL = false>
+template <int LPS, int NCH, bool LINES, bool TAIL = false, bool FULLT = false>
 __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, const int halt = 0)
 {
     constexpr int NG = 256 / LPS, TP = LPS * NCH;
@@ -1319,21 +1322,19 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
     else it = v.sto_items[blk];
     // `halt`: the caller's halt word, loaded but not yet looked at: it travels with the first storage's rows (looked at
     // below, once those loads have been issued; nothing is stored before that. Uniform; -1 = halted)
-    const int T = v.T, N = v.N;
+    const int T = FULLT ? LPS * NCH : v.T, N = v.N;
     const double w = v.w_prox, gam = v.gamma;
     const double a0 = w + gam, ia0 = 1.0 / a0, idet0 = 1.0 / (a0 * a0 - gam * gam), s20 = 2.0 / (a0 + gam);
     const int tbase = li * NCH;
     double *nuL = red + grp * TP, *base = baseL + grp * TP, *lo_ = loL + grp * TP, *hi_ = hiL + grp * TP, *fd_ = fdL + grp * TP;
 
-    double th0[NCH], accQ[NCH];
+    double accQ[NCH];
     double accCost = 0.0;
     int anyFail = 0;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int t = tbase + c;
-        accQ[c] = 0.0;
-        th0[c] = (!LINES && t < T) ? v.price[it.node + N * t] + gam * v.s[t] : 0.0;
-    }
+    for (int c = 0; c < NCH; ++c) accQ[c] = 0.0;
+    // (price + gamma * imbalance of a step is read per storage pass, with its rows, instead of held across the solve: the
+    // kernel sits at its register limit and a pass's second read of two cached doubles costs less than six registers)
     // with lines: a (node, timestep) whose table is empty — no kink of Psi inside the node's window, the usual case —
     // is the copper-plate closed form with (Psi(0), slope) in place of (theta, gamma): cached here, no table reads
     double lp0[NCH], lkap[NCH];
@@ -1390,7 +1391,8 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
             run += c0 - d0;
             if (LINES) { A0[c] = d0; B0[c] = c0; }
             else {
-                const double theta = th0[c] - gam * (d0 - c0);
+                const double th0 = t < T ? v.price[it.node + N * t] + gam * v.s[t] : 0.0;
+                const double theta = th0 - gam * (d0 - c0);
                 A0[c] = w * d0 - mc - theta; B0[c] = w * c0 - mc + theta;
             }
         }
@@ -1538,9 +1540,8 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
                     for (int c = 0; c < NCH; ++c) {
                         double du = INFINITY, dn = INFINITY;
                         if (tbase + c < T) {
-                            double dd, cc, s1, bD, bC;
-                            eval(c, nuv[c], dd, cc, s1);
-                            kinks(c, dd, cc, bD, bC);
+                            double bD, bC;
+                            kinks(c, Dv[c], Cv[c], bD, bC);          // (D, C) of this Newton iteration's evaluation at nuv[c]
                             const double wp = w * pm;
                             const double cand[4] = {bD, bD - wp, bC, bC + wp};
 #pragma unroll
@@ -1869,14 +1870,14 @@ __global__ __launch_bounds__(256, DOPF_WARM_WAVES) void k_sto_warm(DevView v)
 
 // Warm start and, in the same block, the cold scan for what it left over: one launch for the storages of the big
 // copper-plate grids (the separate k_sto_update launch mostly found nothing to do).
-template <int LPS, int NCH, bool LINES, bool TAIL>
+template <int LPS, int NCH, bool LINES, bool TAIL, bool FULLT>
 __global__ __launch_bounds__(256, 3) void k_sto(DevView v)
 {
     // (TAIL: the generator launch in front of this one has added its sums; the grid's last block is the tail block)
     if (TAIL && (int)blockIdx.x == v.nStoItems) { tail_block(v.self); return; }
-    const int left = sto_warm_body<LPS, NCH, LINES, TAIL>(v, blockIdx.x, v.st->halt);   // (with something left over it ends on a
-    if (left < 0) return;                                                                // __syncthreads: the sto_fail flags are visible)
-    sto_cold_body<LPS, NCH, LINES, TAIL>(v, blockIdx.x, left);
+    const int left = sto_warm_body<LPS, NCH, LINES, TAIL, FULLT>(v, blockIdx.x, v.st->halt);   // (with something left over it ends on a
+    if (left < 0) return;                                                                       // __syncthreads: the sto_fail flags are visible)
+    sto_cold_body<LPS, NCH, LINES, TAIL, FULLT>(v, blockIdx.x, left);
 }
 
 // All x-updates of one copper-plate iteration in ONE launch: blocks [0, nStoItems) solve storages (warm start,
@@ -1886,7 +1887,7 @@ __global__ __launch_bounds__(256, 3) void k_sto(DevView v)
 // ones (interleaving the two kinds in dispatch order starts the last storage blocks late and costs 50 %).
 // The launch runs at the storage code's 3 waves/SIMD, which starves the streaming generator blocks once the
 // grid is large, so dopf_create only fuses grids whose storage blocks are all resident from the start.
-template <int LPS, int NCH, bool SKIP, bool TAIL>
+template <int LPS, int NCH, bool SKIP, bool TAIL, bool FULLT>
 __global__ __launch_bounds__(256, 3) void k_agents(DevView v)
 {
     const int nS = v.nStoItems;
@@ -1901,8 +1902,8 @@ __global__ __launch_bounds__(256, 3) void k_agents(DevView v)
         else gen_pair_body<256, TAIL, true>(v, blockIdx.x - nS);
     } else {
         if ((int)blockIdx.x < nS) {
-            const int left = sto_warm_body<LPS, NCH, false, TAIL>(v, blockIdx.x, v.st->halt);   // (with something left over it ends on a
-            if (left >= 0) sto_cold_body<LPS, NCH, false, TAIL>(v, blockIdx.x, left);            // __syncthreads: the sto_fail flags are visible)
+            const int left = sto_warm_body<LPS, NCH, false, TAIL, FULLT>(v, blockIdx.x, v.st->halt);   // (with something left over it ends on a
+            if (left >= 0) sto_cold_body<LPS, NCH, false, TAIL, FULLT>(v, blockIdx.x, left);            // __syncthreads: the sto_fail flags are visible)
         } else {
             if (v.st->halt) return;
             gen_pair_skip_body<256, TAIL>(v, blockIdx.x - nS);
@@ -1940,8 +1941,19 @@ template <int LPS, int NCH>
 static void launch_sto_t(const DevView &v, hipStream_t s)
 {
     if (v.use_warm && v.L == 0) {            // (NCH <= 3 whenever the warm start is on)
-        if (v.tail) hipLaunchKernelGGL((k_sto<LPS, (NCH <= 3 ? NCH : 3), false, true>), dim3(v.nStoItems + 1), dim3(256), 0, s, v);
-        else hipLaunchKernelGGL((k_sto<LPS, (NCH <= 3 ? NCH : 3), false, false>), dim3(v.nStoItems), dim3(256), 0, s, v);
+        constexpr int NC = NCH <= 3 ? NCH : 3;
+#ifdef DOPF_NO_FULLT
+        const bool full = false;
+#else
+        const bool full = v.T == LPS * NC;
+#endif
+        if (v.tail) {
+            if (full) hipLaunchKernelGGL((k_sto<LPS, NC, false, true, true>), dim3(v.nStoItems + 1), dim3(256), 0, s, v);
+            else hipLaunchKernelGGL((k_sto<LPS, NC, false, true, false>), dim3(v.nStoItems + 1), dim3(256), 0, s, v);
+        } else {
+            if (full) hipLaunchKernelGGL((k_sto<LPS, NC, false, false, true>), dim3(v.nStoItems), dim3(256), 0, s, v);
+            else hipLaunchKernelGGL((k_sto<LPS, NC, false, false, false>), dim3(v.nStoItems), dim3(256), 0, s, v);
+        }
         return;
     }
     // with lines the two kernels stay apart: fused, the warm part runs 40 % slower (255 VGPRs, measured)
@@ -1955,13 +1967,19 @@ template <int LPS, int NCH>
 static void launch_agents_t(const DevView &v, hipStream_t s)
 {
     const dim3 grid(v.nStoItems + (v.genBlocks > 0 && !v.genSkip ? v.genBlocks : v.nGenItems) + (v.tail ? 1 : 0));
+#ifdef DOPF_NO_FULLT
+    const bool fullA = false;
+#else
+    const bool fullA = v.T == LPS * NCH;
+#endif
+#define DOPF_AG(SKIP_, TAIL_) { if (fullA) hipLaunchKernelGGL((k_agents<LPS, NCH, SKIP_, TAIL_, true>), grid, dim3(256), 0, s, v); \
+                              else hipLaunchKernelGGL((k_agents<LPS, NCH, SKIP_, TAIL_, false>), grid, dim3(256), 0, s, v); }
     if (v.tail) {
-        if (v.genSkip) hipLaunchKernelGGL((k_agents<LPS, NCH, true, true>), grid, dim3(256), 0, s, v);
-        else hipLaunchKernelGGL((k_agents<LPS, NCH, false, true>), grid, dim3(256), 0, s, v);
+        if (v.genSkip) DOPF_AG(true, true) else DOPF_AG(false, true)
     } else {
-        if (v.genSkip) hipLaunchKernelGGL((k_agents<LPS, NCH, true, false>), grid, dim3(256), 0, s, v);
-        else hipLaunchKernelGGL((k_agents<LPS, NCH, false, false>), grid, dim3(256), 0, s, v);
+        if (v.genSkip) DOPF_AG(true, false) else DOPF_AG(false, false)
     }
+#undef DOPF_AG
 }
 
 void launch_agents_fused(const DevView &v, const Launch &lc, hipStream_t s)
