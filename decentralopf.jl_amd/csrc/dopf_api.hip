@@ -478,6 +478,16 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         v.tailDev = tvd;
     }
     v.splitDual = getenv("DOPF_SPLIT_DUAL") ? 1 : 0;
+    {
+        // networks whose dual step is the one-launch kernel (k_dual_price_t1024: <= 256 lines and nodes, consensus state beyond the
+        // one-block kernel): it builds the tables too, with as many waves as find LDS scratch (<= 8) next to its own ~30 KB
+        const size_t n1 = std::max(NT, LT);
+        const size_t per_wave = (4 * (size_t)v.M2 + 1) * sizeof(double), own = 25 * 1024 + ((size_t)N + 3 * (size_t)L) * sizeof(double);
+        int tw = 0;
+        if (L > 0 && L <= 256 && N <= 256 && n1 > kSmallConsensus && !v.splitDual && !getenv("DOPF_TABLES_LAUNCH"))
+            tw = (int)std::min<size_t>(8, (128 * 1024 - std::min<size_t>(own, 128 * 1024)) / per_wave);
+        v.tablesInDual = tw;
+    }
     double *cons = nullptr;
     TRY(dev_alloc(c, &cons, NT + 2 * LT + 1));
     c->own_cons = cons;

@@ -62,6 +62,8 @@ struct DevView {
     int genBlocks;                  // > 0 (needs genChunk): the fused launch has this many generator blocks, each walking items b, b + genBlocks, ...
     int debugLeave;                 // DOPF_F_DEBUG_LEAVE (tests)
     int coldInWarm;                 // networks: k_sto_warm calls the scan body itself for what it leaves over (no k_sto_update launch)
+    int tablesInDual;               // > 0 (networks on the one-launch dual/price kernel): that kernel builds the breakpoint tables of its
+                                    // timestep itself, with this many waves; no k_tables launch
     int splitDual;                  // (experiments, DOPF_SPLIT_DUAL=1) networks: dual and price steps as two launches
     int stoChunk;                   // > 0: one node, storage item i = storages [i*stoChunk, (i+1)*stoChunk)
     int genChunk;                   // > 0: one node, generator item i = rows [i*genChunk, (i+1)*genChunk) (no item look-up)

@@ -62,16 +62,13 @@ __device__ __forceinline__ double wave_sum64(double x)
     return x;
 }
 
-__global__ __launch_bounds__(64) void k_tables(DevView v)
+// one wave builds the table of (n, t); shm: 4 * 2L + 1 doubles of LDS of the wave's own
+__device__ __forceinline__ void build_table(const DevView &v, const int n, const int t, double *shm)
 {
-    if (v.st->halt) return;
-    extern __shared__ double shm[];
     const int N = v.N, L = v.L, M2 = v.M2;
     double *key = shm, *jmp = shm + M2, *skey = shm + 2 * M2, *sslope = shm + 3 * M2;   // sslope: M2 + 1
-    const int lane = threadIdx.x;
-    const size_t at = blockIdx.x;
-    const int n = (int)(at % N), t = (int)(at / N);
-    if (v.tab_skip[t]) return;               // linear inside every window: the price kernel wrote Psi(0) and the slope
+    const int lane = threadIdx.x & 63;
+    const size_t at = (size_t)n + (size_t)N * t;
     const double w2 = 2.0 * v.w_flow, g = v.gamma, act = g / (w2 + g);
     const double W = v.node_win[n];
 
@@ -169,11 +166,22 @@ __global__ __launch_bounds__(64) void k_tables(DevView v)
         v.tb_m[at] = c;
         v.tb_psi0[at] = psiZ;
     }
+    __builtin_amdgcn_wave_barrier();         // (the wave's LDS scratch is free for its next table)
+}
+
+__global__ __launch_bounds__(64) void k_tables(DevView v)
+{
+    if (v.st->halt) return;
+    extern __shared__ double shm[];
+    const size_t at = blockIdx.x;
+    const int n = (int)(at % v.N), t = (int)(at / v.N);
+    if (v.tab_skip[t]) return;               // linear inside every window: the price kernel wrote Psi(0) and the slope
+    build_table(v, n, t, shm);
 }
 
 void launch_tables(const DevView &v, hipStream_t s)
 {
-    if (v.L == 0) return;
+    if (v.L == 0 || v.tablesInDual) return;  // (tablesInDual: the dual/price kernel builds the tables of its timestep itself)
     const size_t shm = (size_t)(4 * v.M2 + 1) * sizeof(double);
     static bool big_lds = false;
     if (shm > 64 * 1024 && !big_lds) {     // worst case (every kink inside the window) needs 4 * 2L doubles
@@ -1213,6 +1221,17 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         }
     }
     if (tid == 0) { v.walk_any[t] = anyNeed ? 1 : 0; v.tab_skip[t] = lin ? 1 : 0; }
+    if (!lin && v.tablesInDual) {
+        // A line's switch point lies inside some node's window: this timestep's tables are built HERE, by this block's
+        // waves (node n by wave n % tablesInDual, each wave with LDS scratch of its own behind the kernel's other dynamic
+        // LDS), from the prices, flows and mean slacks the block has just stored — instead of by a launch of their own
+        // (k_tables) that in the settled state finds nothing to do: 5 us + a kernel boundary per iteration.
+        __syncthreads();                             // this block's stores above are visible to all its waves
+        const int TW = v.tablesInDual, wv = tid >> 6;
+        double *tsh = sh + N + 3 * L + (size_t)wv * (4 * v.M2 + 1);
+        if (wv < TW)
+            for (int nn = wv; nn < N; nn += TW) build_table(v, nn, t, tsh);
+    }
     if (UPDATE) {
         // residual maxima of this timestep, then the ticket: whoever is last has every block's maxima behind it
         if (tid == 0) {
@@ -1438,6 +1457,19 @@ __global__ __launch_bounds__(256) void k_dual_price_small(DevView v, XchgView x)
     }
 }
 
+// dynamic LDS of k_dual_price_t1024: its own vectors, plus table scratch for tablesInDual waves
+static size_t t1024_lds(const DevView &v)
+{
+    const size_t bytes = ((size_t)v.N + 3 * (size_t)v.L + (size_t)v.tablesInDual * (4 * (size_t)v.M2 + 1)) * sizeof(double);
+    static bool raised = false;
+    if (bytes > 48 * 1024 && !raised) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_dual_price_t1024<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_dual_price_t1024<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        raised = true;
+    }
+    return bytes;
+}
+
 void launch_dual(const DevView &v, hipStream_t s, const XchgView *xd)
 {
     const size_t NT = (size_t)v.N * v.T, LT = (size_t)v.L * v.T;
@@ -1448,7 +1480,7 @@ void launch_dual(const DevView &v, hipStream_t s, const XchgView *xd)
         return;
     }
     if (v.L > 0 && v.L <= 256 && v.N <= 256 && !v.splitDual) {
-        hipLaunchKernelGGL(k_dual_price_t1024<true>, dim3(v.T), dim3(1024), ((size_t)v.N + 3 * (size_t)v.L) * sizeof(double), s, v);
+        hipLaunchKernelGGL(k_dual_price_t1024<true>, dim3(v.T), dim3(1024), t1024_lds(v), s, v);
         return;
     }
     if ((size_t)std::max(v.N, 3 * v.L) * sizeof(double) <= 48 * 1024) {
@@ -1530,7 +1562,7 @@ void launch_derive(const DevView &v, hipStream_t s, bool from_primal)
         return;
     }
     if (v.L > 0 && v.L <= 256 && v.N <= 256 && !v.splitDual) {
-        hipLaunchKernelGGL(k_dual_price_t1024<false>, dim3(v.T), dim3(1024), ((size_t)v.N + 3 * (size_t)v.L) * sizeof(double), s, v);
+        hipLaunchKernelGGL(k_dual_price_t1024<false>, dim3(v.T), dim3(1024), t1024_lds(v), s, v);
         return;
     }
     if ((size_t)std::max(v.N, 3 * v.L) * sizeof(double) <= 48 * 1024) {
