@@ -17,6 +17,13 @@
 
 namespace dopf {
 
+// rows of the PTDF matrix a thread keeps in flight in the dot products of the network kernels (every sum stays in index
+// order: the batch size does not change a bit of the result)
+#ifndef DOPF_PTDF_FLIGHT
+#define DOPF_PTDF_FLIGHT 16
+#endif
+constexpr int kFlight = DOPF_PTDF_FLIGHT;
+
 __device__ __forceinline__ double dmax0(double a) { return a > 0.0 ? a : 0.0; }
 
 // deterministic block sum (256 threads), result broadcast to all threads
@@ -495,12 +502,12 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
                 const double a = which ? c0.aK : c0.aU;
                 if (a > 0.0) {
                     double dot = 0.0, cnt = 0.0;
-                    for (int n0 = nbeg; n0 < nend; n0 += 16) {
-                        double h[16];
+                    for (int n0 = nbeg; n0 < nend; n0 += kFlight) {
+                        double h[kFlight];
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) h[u] = n0 + u < nend ? v.ptdf[l + (size_t)L * (n0 + u)] : 0.0;
+                        for (int u = 0; u < kFlight; ++u) h[u] = n0 + u < nend ? v.ptdf[l + (size_t)L * (n0 + u)] : 0.0;
 #pragma unroll
-                        for (int u = 0; u < 16; ++u)
+                        for (int u = 0; u < kFlight; ++u)
                             if (n0 + u < nend) { dot += h[u] * sdL[n0 + u]; cnt += naL[n0 + u]; }
                     }
                     partial = which ? cnt * a + (w2 * inv) * dot : cnt * a - (w2 * inv) * dot;
@@ -1133,12 +1140,12 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
     }
     double f = 0.0;
     if (l < L)
-        for (int n0 = nbeg; n0 < nend; n0 += 16) {                             // sixteen rows of ptdf in flight (more would spill at 1024 threads)
-            double h[16];
+        for (int n0 = nbeg; n0 < nend; n0 += kFlight) {                        // kFlight rows of ptdf in flight
+            double h[kFlight];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) h[u] = n0 + u < nend ? v.ptdf[l + (size_t)L * (n0 + u)] : 0.0;
+            for (int u = 0; u < kFlight; ++u) h[u] = n0 + u < nend ? v.ptdf[l + (size_t)L * (n0 + u)] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) f += h[u] * (n0 + u < nend ? q[n0 + u] : 0.0);
+            for (int u = 0; u < kFlight; ++u) f += h[u] * (n0 + u < nend ? q[n0 + u] : 0.0);
         }
     red[0][tid] = f;
     __syncthreads();
@@ -1195,12 +1202,12 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
     const int Lc = (((L + P - 1) / P) + 7) & ~7, lbeg = pp * Lc, lend = min(L, lbeg + Lc);
     double pr = 0.0, psx = 0.0, sl = 0.0;
     if (n < N && (nz || lin))
-        for (int l0 = lbeg; l0 < lend; l0 += 16) {                             // ptdfT[n + N l]: coalesced over the nodes
-            double h[16];
+        for (int l0 = lbeg; l0 < lend; l0 += kFlight) {                        // ptdfT[n + N l]: coalesced over the nodes
+            double h[kFlight];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) h[u] = l0 + u < lend ? v.ptdfT[n + (size_t)N * (l0 + u)] : 0.0;
+            for (int u = 0; u < kFlight; ++u) h[u] = l0 + u < lend ? v.ptdfT[n + (size_t)N * (l0 + u)] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < kFlight; ++u) {
                 if (l0 + u < lend) {
                     pr += h[u] * dd[l0 + u];
                     if (lin) { psx += h[u] * Gl[l0 + u]; sl += h[u] * h[u] * Sl[l0 + u]; }
