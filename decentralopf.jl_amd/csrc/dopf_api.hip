@@ -170,8 +170,15 @@ void drop_graphs(dopf_ctx *c)
 
 int read_status(dopf_ctx *c)
 {
-    HIPCHK(c, hipMemcpyAsync(&c->host_st, c->v.st, sizeof(Status), hipMemcpyDeviceToHost, c->main));
+    // (every dopf_iterate ends here: on short calls — 20 iterations of 30 us — the read-back is a visible share of the call)
+    if (!c->host_pin && hipHostMalloc((void **)&c->host_pin, sizeof(Status), hipHostMallocDefault) != hipSuccess) {
+        c->host_pin = nullptr;
+        (void)hipGetLastError();
+    }
+    Status *dst = c->host_pin ? c->host_pin : &c->host_st;
+    HIPCHK(c, hipMemcpyAsync(dst, c->v.st, sizeof(Status), hipMemcpyDeviceToHost, c->main));
     HIPCHK(c, hipStreamSynchronize(c->main));
+    if (c->host_pin) c->host_st = *c->host_pin;
     return DOPF_OK;
 }
 
@@ -525,6 +532,7 @@ void dopf_destroy(dopf_ctx *c)
     for (void *p : c->allocs) hipFree(p);
     if (c->evFork) hipEventDestroy(c->evFork);
     if (c->evJoin) hipEventDestroy(c->evJoin);
+    if (c->host_pin) hipHostFree(c->host_pin);
     if (c->side) hipStreamDestroy(c->side);
     if (c->own_main && c->main) hipStreamDestroy(c->main);
     delete c;

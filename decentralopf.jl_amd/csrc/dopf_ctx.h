@@ -22,6 +22,7 @@ struct dopf_ctx {
     void *own_cons = nullptr;
     std::vector<int> gen_perm, sto_perm;   // sorted position -> caller's index
     dopf::Status host_st{};
+    dopf::Status *host_pin = nullptr;       // page-locked landing area of the status read-back (a pageable target is staged: slower)
     unsigned long long solver_fail_seen = 0;   // failures already reported through DOPF_E_SOLVER
     dopf_comm_state *comm = nullptr;       // non-null: dopf_iterate runs local_update -> all-reduce -> apply_consensus
     char err[512] = {0};

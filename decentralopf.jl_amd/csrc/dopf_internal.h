@@ -102,7 +102,7 @@ struct DevView {
     double *part_ginj, *part_gcost;                 // [item*T + t], [item]
     double *part_sinj, *part_scost;                 // storage scan kernel, per item
     double *part_sinj_w, *part_scost_w;             // storage warm-start kernel, per item
-    double *nu_prev;                                // [t + T*s] price of stored energy of the last solve
+    double *nu_prev;                                // [t + T*s] price of stored energy of the last solve (copper plates: + the step's price offset theta)
     int *nu_valid, *sto_fail, *item_fail;           // [s], [s], [item] (= storages of the item the warm start left over)
     double *part_U, *part_K;                        // [(n + N*t)*L + l]: only the entries k_slack had to walk agent by agent
     double *node_dsum;                              // [n + N*t] change of the node's injection in this iteration (L > 0)

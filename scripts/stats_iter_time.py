@@ -12,7 +12,7 @@ pp = synth.baseline_config(idx); A = pp.G + pp.S
 _capi._pin_hip_runtime()
 sapi = _capi.CApi("scripts/tmp/libdopf_stats.so", "dopf_")
 es = _capi.Engine(sapi, params=_capi.default_params(gamma=gmul/A, eps=0.0), **pp.engine_kwargs())
-e = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=gmul/A, eps=0.0), **pp.engine_kwargs())
+e = _capi.Engine(_capi.CApi(os.environ["DOPF_LIB"], "dopf_") if os.environ.get("DOPF_LIB") else _capi.hip_api(), params=_capi.default_params(gamma=gmul/A, eps=0.0), **pp.engine_kwargs())
 def stats():
     out = (C.c_uint64 * 15)(); sapi.lib.dopf_debug_stats(es._ctx, out); return np.array(list(out), dtype=np.float64)
 s0 = stats()
