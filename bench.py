@@ -465,7 +465,7 @@ def main():
     # left in there, whatever W and K are).
     # With N > 1 ranks the replay is rank 0's own grid as a single-GPU problem (its own demand, gamma = 1/A_local): the
     # kernels one GPU runs per iteration, without the collective.
-    timing = steady = None
+    timing = steady = dev_it_ms = None
     steady_from = 0
     if rank == 0:
         if world > 1:
@@ -494,6 +494,17 @@ def main():
             er.iterate(steady_from - args.warmup - args.steps)
         steady = er.iterate_timed(max(1, args.timed_iters))
         er.close()
+        # ... and once more through the graphs with an event in front of the first launch and one behind the last
+        # (DOPF_F_TIME_CALLS): the device-side per-iteration time of the timed region's iterations — the wall-clock
+        # figure above also carries the host's launch latency and the status read-back of the call, which on a short
+        # region (20 iterations) is a tenth of it
+        et = _capi.Engine(_capi.hip_api(), params=_capi.default_params(gamma=g_r, w_flow=wf_r, eps=0.0, device=local_rank,
+                                                                       flags=args.flags | _capi.F_TIME_CALLS), **ppr.engine_kwargs())
+        clock_warm()
+        et.iterate(args.warmup)
+        et.iterate(args.steps)
+        dev_it_ms = et.last_call_ms() / args.steps if et.last_call_ms() > 0 else None
+        et.close()
 
     if rank == 0:
         gen_b, sto_b, shared_b = algorithmic_bytes(pp.G, pp.S, pp.T, pp.N, pp.L)
@@ -540,13 +551,13 @@ def main():
                        ([] if tail else ["reduce_ms", "dual_ms"])
 
             def overhead(tm, per_iter_ms):
-                if world > 1:            # (the replay is one rank's grid without the exchange: nothing to calibrate against)
-                    return 0.5 * tm["empty_ms"]
                 return min(tm["empty_ms"], max(0.0, (sum(tm[k] for k in launched) - per_iter_ms) / len(launched)))
-            ov = overhead(timing, it_ms)
-            one_launch = fused and tail and world == 1
+            # per-iteration time of the graph replay on the device (events around the call's launches); rank 0's own grid when N > 1
+            ref_it_ms = dev_it_ms if dev_it_ms else it_ms
+            ov = overhead(timing, ref_it_ms)
+            one_launch = fused and tail
             # one launch per iteration: the per-iteration time of the graph replay IS the launch (plus its one kernel boundary)
-            k_ms = it_ms if one_launch else max(timing["gen_ms"] - ov, 1e-6)
+            k_ms = ref_it_ms if one_launch else max(timing["gen_ms"] - ov, 1e-6)
             traffic, traffic_source = None, None       # HBM bytes per launch from the committed PMC passes (scripts/profile.sh)
             for tag in ("r03", "r02", "r01"):
                 pmc_file = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
@@ -560,7 +571,7 @@ def main():
             # steady state: its own per-iteration time is not measured with the graph; same overhead as the timed region
             ks_ms = max(steady["gen_ms"] - ov, 1e-6)
             if one_launch:
-                ks_ms = max(steady["iter_ms"] - (timing["iter_ms"] - it_ms), 1e-6)
+                ks_ms = max(steady["iter_ms"] - (timing["iter_ms"] - ref_it_ms), 1e-6)
             # Row skipping moves fewer bytes than the 16T+20 B/update model: algorithmic bytes / time would exceed what the
             # memory system did (and the 8 TB/s peak). The roofline fraction is then taken from the MEASURED traffic.
             basis_b, basis = alg_b, "algorithmic bytes (SURVEY.md 8d model)"
@@ -573,10 +584,12 @@ def main():
                                "bytes_basis": basis,
                                "algorithmic_bytes_per_launch": alg_b,
                                "kernel_ms": k_ms,
-                               "kernel_ms_basis": ("per-iteration time of the timed region's graph replay: the iteration is this ONE launch (x-updates, "
-                                                   "consensus sum, dual step, stop test) plus its kernel boundary") if one_launch else
+                               "kernel_ms_basis": ("device-side per-iteration time of the timed region's graph replay (events around the call's launches, "
+                                                   "DOPF_F_TIME_CALLS): the iteration is this ONE launch (x-updates, consensus sum, dual step, stop test) "
+                                                   "plus its kernel boundary") if one_launch else
                                                   ("HIP events on the kernels' stream over the timed region's iterations (replayed), net of the event "
-                                                   "overhead that makes the iteration's kernels add up to the graph replay's per-iteration time"),
+                                                   "overhead that makes the iteration's kernels add up to the graph replay's device-side per-iteration time"),
+                               "device_ms_per_iteration": dev_it_ms,
                                "kernel_ms_events_raw": timing["gen_ms"], "event_overhead_ms": ov, "empty_event_pair_ms": timing["empty_ms"],
                                "window": f"the timed region: iterations {args.warmup + 1}..{args.warmup + args.steps} from the zero state",
                                "steady_state": {"kernel_ms": ks_ms, "achieved": basis_b / (ks_ms * 1e-3) / 1e9,

@@ -59,6 +59,7 @@ F_OVERLAP_AGENTS = 2
 F_NO_WARM_START = 4
 F_NO_ROW_SKIP = 8
 F_NO_TAIL_FUSE = 4096
+F_TIME_CALLS = 8192
 F_NO_FUSE = 16
 F_COMM_HOST = 64
 F_DEBUG_ROOT_CAP = 128
@@ -139,6 +140,7 @@ class CApi:
             self._sig("central_solve", C.c_int, [C.POINTER(DopfProblem), C.POINTER(DopfParams), C.c_double, C.c_int32,
                                                  C.POINTER(DopfCentralResult)] + [c_double_p] * 9)
             self._sig("get_node_results", C.c_int, [ctxp, c_double_p, c_double_p, c_double_p])
+            self._sig("last_call_ms", C.c_double, [ctxp])
             # consensus sum across GPUs inside the library (RCCL, loaded on first use)
             self._sig("comm_unique_id", C.c_int, [C.c_void_p])
             self._sig("comm_init", C.c_int, [ctxp, C.c_int32, C.c_int32, C.c_void_p])
@@ -300,6 +302,10 @@ class Engine:
         outs = [np.zeros(self.N * self.T) for _ in range(3)]
         self._chk(self.api.get_node_results(self._ctx, *[_dp(o) for o in outs]))
         return tuple(o.reshape(self.T, self.N).T.copy() for o in outs)
+
+    def last_call_ms(self) -> float:
+        """F_TIME_CALLS: device-side milliseconds of the last iterate() call's launches (-1 if not measured)."""
+        return float(self.api.last_call_ms(self._ctx))
 
     def solver_failures(self) -> int:
         return int(self.api.solver_failures(self._ctx))

@@ -533,6 +533,8 @@ void dopf_destroy(dopf_ctx *c)
     if (c->evFork) hipEventDestroy(c->evFork);
     if (c->evJoin) hipEventDestroy(c->evJoin);
     if (c->host_pin) hipHostFree(c->host_pin);
+    if (c->evT0) hipEventDestroy(c->evT0);
+    if (c->evT1) hipEventDestroy(c->evT1);
     if (c->side) hipStreamDestroy(c->side);
     if (c->own_main && c->main) hipStreamDestroy(c->main);
     delete c;
@@ -564,6 +566,13 @@ int dopf_iterate(dopf_ctx *c, int32_t n_iters, int32_t *iters_done, int32_t *con
     }
     // Enqueue in slices and look at the device status word between slices, so that a converged (or capped)
     // run stops being fed no-op launches; one sync per kCheckEvery iterations costs nothing measurable.
+    // DOPF_F_TIME_CALLS (measurement): an event in front of the call's first launch and one behind its last — the device-side
+    // span of the call's iterations, without the host's launch latency in front and the status read-back behind
+    const bool timed = (c->q.flags & DOPF_F_TIME_CALLS) != 0 && n_iters > 0;
+    if (timed) {
+        if (!c->evT0) { HIPCHK(c, hipEventCreate(&c->evT0)); HIPCHK(c, hipEventCreate(&c->evT1)); }
+        HIPCHK(c, hipEventRecord(c->evT0, c->main));
+    }
     int left = n_iters;
     while (left > 0) {
         int slice = std::min(left, kCheckEvery);
@@ -576,15 +585,23 @@ int dopf_iterate(dopf_ctx *c, int32_t n_iters, int32_t *iters_done, int32_t *con
             for (; slice > 0; --slice) HIPCHK(c, hipGraphLaunch(c->graph1, c->main));
         }
         HIPCHK(c, hipGetLastError());
+        if (timed && left == 0) HIPCHK(c, hipEventRecord(c->evT1, c->main));
         const int rc = read_status(c);
         if (rc) return rc;
         if (c->host_st.halt) break;
+    }
+    c->last_call_ms = -1.0;
+    if (timed && left == 0) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->evT0, c->evT1) == hipSuccess) c->last_call_ms = (double)ms;
     }
     if (n_iters == 0) { const int rc = read_status(c); if (rc) return rc; }
     if (iters_done) *iters_done = c->host_st.iters_total - before;
     if (converged) *converged = c->host_st.converged;
     return check_solver(c);
 }
+
+double dopf_last_call_ms(const dopf_ctx *c) { return c ? c->last_call_ms : -1.0; }
 
 int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
 {

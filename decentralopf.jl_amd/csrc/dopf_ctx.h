@@ -16,6 +16,8 @@ struct dopf_ctx {
     hipStream_t main = nullptr, side = nullptr;
     bool own_main = false;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipEvent_t evT0 = nullptr, evT1 = nullptr;      // DOPF_F_TIME_CALLS: around the launches of the last dopf_iterate
+    double last_call_ms = -1.0;
     hipGraphExec_t graph1 = nullptr, graphM = nullptr, graphU = nullptr;   // 1, kMid, kUnroll iterations per launch
     bool graphs_valid = false;
     std::vector<void *> allocs;

@@ -118,6 +118,9 @@ typedef struct dopf_params {
 #define DOPF_F_NO_TAIL_FUSE 4096  /* one node, no lines, single-GPU chain: keep the consensus sums and the dual step as launches of
                                    their own (k_reduce, k_dual_price_small) instead of finishing the iteration inside the
                                    x-update launch (integer accumulators + the last block's tail) */
+#define DOPF_F_TIME_CALLS  8192  /* measurement: dopf_iterate brackets its launches with a HIP event pair on the context's stream;
+                                   dopf_last_call_ms returns the device-side span of the last call's iterations (no host launch
+                                   latency in front, no status read-back behind) */
 #define DOPF_F_DEBUG_LEAVE  2048  /* tests: the active-set storage body declares every third storage uncertified, so that the
                                    hand-over to the scan body is exercised in every kernel variant                        */
 #define DOPF_F_DEBUG_ROOT_CAP 128 /* tests: the scan kernel's root search gives up after 2 iterations instead of
@@ -213,6 +216,9 @@ typedef struct dopf_timing {
                                dual_ms are empty event pairs */
 } dopf_timing;
 int dopf_iterate_timed(dopf_ctx *ctx, int32_t n_iters, dopf_timing *out);
+/* DOPF_F_TIME_CALLS: milliseconds between the first launch of the last dopf_iterate call and the end of its last one, on the
+ * device (-1 without the flag, or when the call ended early on a stop). */
+double dopf_last_call_ms(const dopf_ctx *ctx);
 
 int64_t dopf_solver_failures(dopf_ctx *ctx);
 

@@ -13,7 +13,8 @@ ARGS="bench.py --workload $W --no-side --steps 40 --warmup 60 --timed-iters 2 $X
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $RAW/p1 -- python3 $ARGS > $OUT/p1.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $RAW/p2 -- python3 $ARGS > $OUT/p2.log 2>&1
 python3 - <<PY
-import csv, glob, collections
+import csv, glob, collections, json
+summary = {}
 for p in ("p1","p2"):
     for f in glob.glob("$RAW/%s/**/*counter_collection.csv" % p, recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
@@ -24,4 +25,7 @@ for p in ("p1","p2"):
         for k, d in agg.items():
             if "k_sto" in k or "k_gen" in k or "k_reduce" in k or "k_agents" in k or "k_dual" in k:
                 print(k, {c: round(v / cnt[(k, c)]) for c, v in d.items()})
+                summary.setdefault(k.split("::")[-1], {}).update({c: v / cnt[(k, c)] for c, v in d.items()})
+                summary[k.split("::")[-1]]["launches_averaged"] = max(cnt[(k, c)] for c in d)
+json.dump(summary, open("$OUT/summary.json", "w"), indent=1)
 PY
