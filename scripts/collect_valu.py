@@ -17,7 +17,7 @@ for w in workloads:
     if os.path.exists(f):
         for r in csv.DictReader(open(f)):
             if r["window"].startswith("steady"):
-                dur[r["Name"].split("::")[-1].split("(")[0]] = float(r["AverageNs"])
+                dur[r["Name"].split("(")[0].split("::")[-1]] = float(r["AverageNs"])
     rec = {}
     for k, c in s.items():
         d = dur.get(k)

@@ -9,7 +9,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$W
 RAW=/tmp/dopf_pmc_$W          # raw counter dumps stay on the box (gpurun_out/ is copied back only below 64 MiB)
 rm -rf $RAW; mkdir -p $OUT $RAW
 cd $GRAFT_REPO_ROOT
-ARGS="bench.py --workload $W --no-side --steps 40 --warmup 60 --timed-iters 2 $X"
+ARGS="bench.py --workload $W --no-side --steps 400 --warmup 400 --timed-iters 2 $X"      # ~2 000 launches per kernel: the settled state dominates the means
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $RAW/p1 -- python3 $ARGS > $OUT/p1.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $RAW/p2 -- python3 $ARGS > $OUT/p2.log 2>&1
 python3 - <<PY
