@@ -782,6 +782,11 @@ int dopf_get_primal(dopf_ctx *c, double *P, double *D, double *C, double *E)
     if ((rc = get_rows(c, P, c->v.P, c->gen_perm))) return rc;
     if ((rc = get_rows(c, D, c->v.D, c->sto_perm))) return rc;
     if ((rc = get_rows(c, C, c->v.C, c->sto_perm))) return rc;
+    if (E && c->level_from_primal) {         // the level is rebuilt from D and C (the iteration's kernels do not store it)
+        launch_derive_level(c->v, c->main);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->main));
+    }
     if ((rc = get_rows(c, E, c->v.E, c->sto_perm))) return rc;
     return DOPF_OK;
 }

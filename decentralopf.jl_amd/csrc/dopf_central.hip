@@ -150,6 +150,7 @@ extern "C" int dopf_central_solve(const dopf_problem *p, const dopf_params *q, d
     if ((rc = metrics(v.P, v.D, v.C, cv.yE, cv.yb, cv.yf, 1.0, mf))) return rc;
     res->objective = mf.pobj; res->dual_objective = mf.dobj; res->primal_infeasibility = mf.pinf; res->gap = mf.gap;
     res->iterations = it; res->converged = mf.gap <= tol ? 1 : 0;
+    c->level_from_primal = false;            // (the metrics pass has written the accepted point's levels into v.E)
     if ((rc = dopf_get_primal(c, P, D, C, E))) return rc;
     std::vector<double> yb(T), yf(LT);
     HIPCHK(c, hipMemcpy(yb.data(), cv.yb, sizeof(double) * T, hipMemcpyDeviceToHost));

@@ -3,7 +3,8 @@
 // Layout of everything that lives in HBM (all fp64 unless noted):
 //   P            [t + T*g]      generator output, updated IN PLACE each iteration (the x-update of a
 //                               generator needs only its own previous value), generators sorted by node
-//   D, C, E      [t + T*s]      storage discharge / charge / level, in place, storages sorted by node
+//   D, C         [t + T*s]      storage discharge / charge, in place, storages sorted by node
+//   E            [t + T*s]      storage level = cumsum(C - D): written on request only (dopf_get_primal, the central solver)
 //   dltG, dltS   [t + T*a]      change of the agent's net injection in this iteration (only when L > 0:
 //                               feeds the slack sums sum_a U_a, sum_a K_a)
 //   lam [T], mu/rho [l + L*t]   current duals; *_used = the ones the last solve read
@@ -219,6 +220,7 @@ void launch_xchg(const DevView &v, const XchgView &x, hipStream_t s);   // cons 
 void launch_dual(const DevView &v, hipStream_t s, const XchgView *xd = nullptr);   // xd: peer exchange inside the one-block kernel
 //      // consensus -> duals, residuals, prices, status
 void launch_derive(const DevView &v, hipStream_t s, bool from_primal);
+void launch_derive_level(const DevView &v, hipStream_t s);            // E = cumsum(C - D) into v.E
 void launch_node_results(const DevView &v, double *gen, double *dis, double *chg, hipStream_t s);   // [n + N*t] each, device pointers   // consensus -> inj/s/flow/price (no dual step)
 
 }  // namespace dopf

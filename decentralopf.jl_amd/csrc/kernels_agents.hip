@@ -1112,7 +1112,8 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
                 const size_t e = (size_t)s * T + (tbase + c);
                 v.D[e] = Dn[c];
                 v.C[e] = Cn[c];
-                v.E[e] = ev;
+                // (the level is not stored: nothing on the path reads it back — a solve takes its contacts from cumsum(C - D) of
+                // the rows it loads anyway — and dopf_get_primal rebuilds it on request; 8T bytes per storage and iteration less)
                 if (LINES && (v.keepDeltas || v.walk_any[tbase + c])) v.dltS[e] = (Dn[c] - Cn[c]) - (D0[c] - C0[c]);
                 v.nu_prev[e] = LINES ? nuf[c] : nuf[c] + (th0[c] - gam * (D0[c] - C0[c]));      // (nu + theta: see the active-set body)
                 accQ[c] += Dn[c] - Cn[c];
@@ -1757,7 +1758,6 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
                         const size_t e = (size_t)s * T + t;
                         v.D[e] = Dv[c];
                         v.C[e] = Cv[c];
-                        v.E[e] = bs[c] + px[c];
                         // (nu + theta, see the loads; theta back from the step's offsets: B0 - A0 = w (c0 - d0) + 2 theta. Kept in
                         // registers: a second array of solver state in memory cost 1.2 us per iteration, the registers nothing)
                         v.nu_prev[e] = LINES ? nuc[c] : nuc[c] + 0.5 * (B0[c] - A0[c] - w * dq[c]);

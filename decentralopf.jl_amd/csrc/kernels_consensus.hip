@@ -1549,6 +1549,12 @@ __global__ __launch_bounds__(256) void k_node_results(DevView v, double *gen, do
     }
 }
 
+// ResultStorage.level (results.jl:4): E = cumsum(C - D), on request (the solve kernels do not store it)
+void launch_derive_level(const DevView &v, hipStream_t s)
+{
+    if (v.S > 0) hipLaunchKernelGGL(k_derive_level, dim3((unsigned)((v.S + 255) / 256)), dim3(256), 0, s, v);
+}
+
 void launch_node_results(const DevView &v, double *gen, double *dis, double *chg, hipStream_t s)
 {
     hipLaunchKernelGGL(k_node_results, dim3(v.N * ((v.T + 31) / 32)), dim3(256), 0, s, v, gen, dis, chg);
