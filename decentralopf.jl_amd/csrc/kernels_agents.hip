@@ -1265,6 +1265,26 @@ __device__ __forceinline__ void scan_clamps_rev(double &lo, double &hi, int lane
     }
 }
 
+// prefix (left-to-right) inclusive scan of clamp maps over the lanes of each group: lane l ends up with
+// M_l o ... o M_1 o M_0 (the left-most map is applied first)
+template <int LPS>
+__device__ __forceinline__ void scan_clamps_fwd(double &lo, double &hi, int lane)
+{
+    const int r = lane & ((LPS < 16 ? LPS : 16) - 1);
+#define DOPF_FWD_STEP(CTRL, RM, COND)                                                \
+    {                                                                                \
+        const double glo = dppd<CTRL, RM>(lo, lo), ghi = dppd<CTRL, RM>(hi, hi);     \
+        if (COND) { const double nlo = clampd(glo, lo, hi), nhi = clampd(ghi, lo, hi); lo = nlo; hi = nhi; } \
+    }
+    DOPF_FWD_STEP(0x111, 0xF, r >= 1)                           // row_shr:1
+    if (LPS >= 4) DOPF_FWD_STEP(0x112, 0xF, r >= 2)
+    if (LPS >= 8) DOPF_FWD_STEP(0x114, 0xF, r >= 4)
+    if (LPS >= 16) DOPF_FWD_STEP(0x118, 0xF, r >= 8)
+    if (LPS >= 32) DOPF_FWD_STEP(0x142, 0xA, lane & 16)         // row_bcast:15
+    if (LPS >= 64) DOPF_FWD_STEP(0x143, 0xC, lane & 32)         // row_bcast:31
+#undef DOPF_FWD_STEP
+}
+
 // suffix (right-to-left) inclusive min over the lanes of each group
 template <int LPS>
 __device__ __forceinline__ int scan_min_rev_i(int x, int lane)
@@ -1724,6 +1744,63 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
                         if (flo > fhi + tn) { okk = false; nkind[c] = 0; }      // wrong sign: release the contact
                         nuc[c] = clampd(nuv[c], flo, fmax(flo, fhi));
                     }
+                }
+            }
+            // The same question from the LEFT, asked only when a price jump has the wrong sign somewhere in the wave: the interval a
+            // segment's price may take given everything to its left (an empty contact in front of it caps it at the left price, a
+            // full one floors it). An empty interval releases the contact IN FRONT of the segment, and the inverted bound travels
+            // on. Without it a run of idle contacts that a cheaper segment on its left wants to charge through (a storage that sat
+            // empty for sixteen steps and now starts earlier) lost ONE contact per round from the left — the right-to-left pass
+            // above only sees the first of them: 7 rounds in iteration 8 of config2, 3 with it (prototype: scripts/proto_repair.py,
+            // FWD=4).
+            // Only when the right-to-left pass released a FEW contacts (1..4 of the storage): where it releases many — the zero
+            // state, where every step is a contact — both passes carrying their inverted bounds on release nearly everything,
+            // the next round adds it back, and the rounds cycle (prototype: all storages at the round cap in iteration 1).
+            {
+                int nrel = 0;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) nrel += __popcll(group_bits<LPS>(nkind[c] == 0 && kind[c] != 0, gbase));
+                const bool fwd = nrel >= 1 && nrel <= 4 && !gdone;          // (uniform over the lane group)
+                if (__any(fwd)) {
+                    double Llo = -INFINITY, Lhi = INFINITY, Ulo = -INFINITY, Uhi = INFINITY;     // this lane's composed maps
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        if (tbase + c < T && ISEND(c)) {
+                            // state for the NEXT segment: lower bound max(mlo, .) behind a full contact, none otherwise;
+                            // upper bound min(mhi, .) behind an empty contact, none otherwise
+                            const double l_lo = kind[c] == 2 ? mlo[c] : -INFINITY, l_hi = kind[c] == 2 ? INFINITY : -INFINITY;
+                            const double u_lo = kind[c] == 1 ? -INFINITY : INFINITY, u_hi = kind[c] == 1 ? mhi[c] : INFINITY;
+                            const double a1 = clampd(Llo, l_lo, l_hi), a2 = clampd(Lhi, l_lo, l_hi);
+                            const double b1 = clampd(Ulo, u_lo, u_hi), b2 = clampd(Uhi, u_lo, u_hi);
+                            Llo = a1; Lhi = a2; Ulo = b1; Uhi = b2;
+                        }
+                    }
+                    scan_clamps_fwd<LPS>(Llo, Lhi, lane);
+                    scan_clamps_fwd<LPS>(Ulo, Uhi, lane);
+                    const double leftL = prev_lane<LPS>(Llo), leftU = prev_lane<LPS>(Uhi);       // (maps of the lanes to the left)(-inf), (+inf)
+                    double pin = li == 0 ? -INFINITY : leftL, phin = li == 0 ? INFINITY : leftU;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const int t = tbase + c;
+                        if (t < T && ISEND(c)) {
+                            const double glo = fmax(mlo[c], pin), ghi = fmin(mhi[c], phin);
+                            const double tn = 1e-10 * (1.0 + fmin(fabs(glo), fabs(ghi)));
+                            fd_[t] = glo > ghi + tn ? 1.0 : 0.0;           // (fd_: the Newton loop's scratch, free here; indexed by segment end)
+                            pin = kind[c] == 2 ? glo : -INFINITY;
+                            phin = kind[c] == 1 ? ghi : INFINITY;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const int sendNext = next_lane_i<LPS>(send[0]);        // the segment the next lane's first step belongs to
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const int t = tbase + c;
+                        if (t + 1 < T && ISEND(c) && kind[c] != 0) {
+                            const int sn = c + 1 < NCH ? send[c + 1 < NCH ? c + 1 : c] : sendNext;
+                            if (fwd && fd_[sn] != 0.0) { okk = false; nkind[c] = 0; }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
             // (debugLeave, tests: every third storage is declared uncertified, so that the hand-over to the scan body runs)

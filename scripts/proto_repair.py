@@ -17,6 +17,8 @@ GMUL = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0
 RAND = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 CHAIN_RESET = int(sys.argv[7]) if len(sys.argv) > 7 else 1
 COLD_E = int(sys.argv[8]) if len(sys.argv) > 8 else 0
+FWD = int(os.environ.get("FWD", "0"))
+FWD_MAXREL = int(os.environ.get("FWD_MAXREL", "2"))
 pp = synth.baseline_config(2, scale=scale)
 if RAND:
     rng = np.random.default_rng(5)
@@ -161,6 +163,26 @@ def certificate(st, seginfo, E):
         else:
             flo, fhi = nlo, max(nlo, nhi)
         sg['chosen'] = min(max(sg['nu'], flo), fhi)
+    if FWD and (FWD < 4 or 0 < len(release) <= FWD_MAXREL):
+        # forward pass (left to right): the interval a segment's price may take given everything to its LEFT; an empty
+        # interval releases the contact in front of the segment, and the inverted bound travels on (a run of idle contacts
+        # that a cheaper segment on its left wants to charge through is released in ONE round instead of one contact per round)
+        plo, phi = -np.inf, np.inf
+        prev_end = None
+        for i, sg in enumerate(seginfo):
+            if sg['kind'] != 0 and sg['flat'] and sg['lo'] <= sg['hi'] and sg['nu'] >= sg['lo'] - 1e-9 and sg['nu'] <= sg['hi'] + 1e-9:
+                mlo, mhi = sg['lo'], sg['hi']
+            elif sg['kind'] == 0:
+                mlo = mhi = 0.0
+            else:
+                mlo = mhi = sg['nu']
+            glo, ghi = max(mlo, plo), min(mhi, phi)
+            tn = 1e-10 * (1 + min(abs(glo), abs(ghi)))
+            if glo > ghi + tn and prev_end is not None and (FWD in (2, 4) or sg['a'] == sg['e']):
+                if prev_end not in release: release.append(prev_end)
+            if sg['kind'] == 1: plo, phi = -np.inf, ghi
+            elif sg['kind'] == 2: plo, phi = glo, np.inf
+            prev_end = sg['e']
     add = []
     for sg in seginfo:
         a, e = sg['a'], sg['e']
@@ -207,9 +229,13 @@ def solve_storage(st, D0, C0, th0, stats):
     else:
         kind = kinds_from_E(np.cumsum(C0 - D0), st.em)
         nu_step = st.nu.copy()
+    trace = []
     for rnd in range(RMAX):
         D, C, E, nus, seginfo, nok = solve_round(st, rD0, rC0, kind, nu_step, stats)
         ok, release, add = certificate(st, seginfo, E)
+        trace.append((np.flatnonzero(kind).tolist(), [int(kind[t]) for t in np.flatnonzero(kind)], release, add,
+                      [round(sg['nu'], 3) for sg in seginfo]))
+        st.trace = trace
         if ok and nok:
             for sg in seginfo:
                 if sg['kind'] != 0:
@@ -243,6 +269,10 @@ for k in range(1, NIT + 1):
         D, C, r = solve_storage(st, D0[i], C0[i], th0, stats)
         hist[r] += 1
         depths.append(stats['depth'])
+        if r >= 5 and k >= 4 and os.environ.get("TRACE"):
+            print(f"  storage {i} (pm {st.pm}, em {st.em}) took {r} rounds:")
+            for j, (pos, kd, rel, add, nus_) in enumerate(st.trace):
+                print(f"    round {j}: contacts {list(zip(pos, kd))} prices {nus_} -> release {rel} add {add}")
         if D is not None:
             worst = max(worst, np.abs(D - Dn[i]).max(), np.abs(C - Cn[i]).max())
     print(f"it {k}: rounds hist {hist[1:].tolist()} (last = failed) newton/sto {stats['newton']/S:.1f} flatjumps/sto {stats['flatjump']/S:.2f} worst diff {worst:.2e} | eval depth mean {np.mean(depths):.1f} max {np.max(depths)}", flush=True)
