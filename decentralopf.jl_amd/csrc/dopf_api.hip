@@ -123,7 +123,8 @@ static bool slice_dual(const DevView &v, bool single)
 // the whole tail of the iteration rides in the x-update launch (k_agents / k_sto / the generator kernel): true single-GPU chain only
 static bool tail_fused(const dopf_ctx *c, bool single)
 {
-    return single && c->comm == nullptr && c->v.tailDev != nullptr;
+    // no communicator, or a peer exchange that lives inside the tail block (copper plates; set up by dopf_xchg_init)
+    return single && c->v.tailDev != nullptr && (c->comm == nullptr || c->tail_xchg);
 }
 
 void enqueue_local(dopf_ctx *c, bool single)
@@ -193,8 +194,8 @@ int enqueue_iteration(dopf_ctx *c)
     const bool single = c->comm == nullptr;
     // copper plate + peer exchange: the one-block dual kernel exchanges the vector itself — the single-GPU chain, no extra launch
     const XchgView *xd = comm_xchg(c);
-    if (xd && !(c->v.L == 0 && slice_dual(c->v, true))) xd = nullptr;
-    const bool like_single = single || xd != nullptr;
+    if (xd && !(c->v.L == 0 && slice_dual(c->v, true)) && !c->tail_xchg) xd = nullptr;
+    const bool like_single = single || xd != nullptr;        // (tail_xchg: the launch's tail block exchanges; nothing else is launched)
     enqueue_local(c, like_single);
     if (!like_single) { const int rc = comm_enqueue_allreduce(c); if (rc) return rc; }
     enqueue_apply(c, like_single, xd);

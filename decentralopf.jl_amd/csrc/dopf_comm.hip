@@ -29,6 +29,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -49,6 +50,7 @@ struct dopf_comm_state {
     void *xbuf = nullptr;       // this rank's receive area (fine-grained device memory)
     size_t xbytes = 0;
     std::vector<void *> opened; // IPC mappings of other processes' areas
+    XchgView *xdev = nullptr;   // the view in device memory (the tail block of a one-launch iteration reads it there)
 };
 
 namespace {
@@ -214,6 +216,7 @@ void comm_release(dopf_ctx *c)
     if (c->comm->comm && g_rccl.lib) g_rccl.CommDestroy(c->comm->comm);
     for (void *p : c->comm->opened) hipIpcCloseMemHandle(p);
     if (c->comm->xbuf) hipFree(c->comm->xbuf);
+    if (c->comm->xdev) hipFree(c->comm->xdev);
     delete c->comm;
     c->comm = nullptr;
 }
@@ -307,6 +310,21 @@ void xchg_fill_view(dopf_ctx *c, dopf_comm_state *cs, int world, int rank, void 
         x.sflags[r] = reinterpret_cast<unsigned long long *>((char *)areas[r] + lay.sflags_off);
         x.data[r] = reinterpret_cast<double *>((char *)areas[r] + lay.data_off);
         x.sum[r] = reinterpret_cast<double *>((char *)areas[r] + lay.sum_off);
+    }
+    // Copper plate with one-launch iterations: the launch's tail block holds the rank's whole vector (T sums
+    // and the cost) the moment the last block's adds have landed — it exchanges it itself (all-gather form, one chunk), so a
+    // rank's iteration stays ONE launch. The view goes to device memory, the context's TailView points at it.
+    c->tail_xchg = false;
+    // (T + 1 <= 128: all slots in one pass of the tail block's lane pairs — the flags are published once, behind the whole vector)
+    if (c->v.tailDev && c->v.L == 0 && c->v.N == 1 && lay.n == (size_t)c->v.T + 1 && lay.nchunks == 1 && c->v.T + 1 <= 128 &&
+        !getenv("DOPF_NO_TAIL_XCHG")) {
+        DeviceGuard guard(c->device);
+        bool ok = cs->xdev || hipMalloc((void **)&cs->xdev, sizeof(XchgView)) == hipSuccess;
+        ok = ok && hipMemcpy(cs->xdev, &x, sizeof(XchgView), hipMemcpyHostToDevice) == hipSuccess;
+        const XchgView *dp = cs->xdev;
+        ok = ok && hipMemcpy((char *)const_cast<TailView *>(c->v.tailDev) + offsetof(TailView, xchg), &dp, sizeof dp, hipMemcpyHostToDevice) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        c->tail_xchg = ok;
     }
 }
 

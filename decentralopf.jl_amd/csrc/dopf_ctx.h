@@ -27,6 +27,7 @@ struct dopf_ctx {
     dopf::Status *host_pin = nullptr;       // page-locked landing area of the status read-back (a pageable target is staged: slower)
     unsigned long long solver_fail_seen = 0;   // failures already reported through DOPF_E_SOLVER
     dopf_comm_state *comm = nullptr;       // non-null: dopf_iterate runs local_update -> all-reduce -> apply_consensus
+    bool tail_xchg = false;                // peer exchange inside the tail block of the one-launch iteration (copper plates)
     bool level_from_primal = true;         // dopf_get_primal rebuilds E = cumsum(C - D); false while a central solve's own levels are in v.E
     char err[512] = {0};
 };

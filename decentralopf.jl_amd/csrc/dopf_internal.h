@@ -45,12 +45,15 @@ struct Status {
     int tail_par;           // tail in the launch: which of the two accumulator sets the next launch adds into
 };
 
+struct XchgView;
 // accumulators of the one-launch iterations (kernels_agents.hip); lives in device memory
 struct TailView {
     long long *acc;                 // [2 sets][kAccRep][accStride]: slots 0..T-1 injection sums, slot T cost
     int accStride;
     int expect;                     // blocks that add to every slot (generator blocks + storage items)
     double scaleInj, invInj, scaleCost, invCost;        // fixed-point scales (powers of two) and their inverses
+    const XchgView *xchg;           // non-null (a context joined to a peer exchange): the tail block sums its vector over the ranks
+                                    // itself, between its own sums and the dual step (device copy of the exchange's view)
 };
 
 struct DevView {

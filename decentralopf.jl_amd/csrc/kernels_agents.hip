@@ -148,11 +148,49 @@ __device__ DOPF_TAIL_INLINE void tail_block(const DevView *self)
             if ((round & 255u) == 0u && wall_clock64() - tstart > limit) break;
             __builtin_amdgcn_s_sleep(1);
         }
-        if (!ok) { badT = 1; continue; }
+        if (!ok) atomicOr(&badT, 1);             // (no early way out in front of the exchange's barriers)
         DOPF_TAIL_STAMP(2)
-        if (!act || half) continue;
+        double xsum = t < T ? (double)isum * tv.invInj : (double)isum * tv.invCost;       // this rank's sum of the slot
+        if (tv.xchg) {                           // (only offered when all T + 1 slots fit ONE pass of this loop: dopf_comm.hip)
+            // A context joined to a peer exchange: the sum over the RANKS happens here, between the rank's own
+            // sums and the dual step — the slot's value goes into every peer's receive area, the ranks' copies come back from
+            // the own area and are added in rank order (every rank adds the same numbers in the same order: bitwise the same
+            // duals everywhere). Protocol as k_xchg's, one chunk; the wait is bounded. (Wave-uniform: every lane is here.)
+            const XchgView &x = *tv.xchg;
+            const int W = x.world, rk = x.me;
+            const unsigned long long seq = (unsigned long long)v.st->iters_total + 1ull;
+            const size_t xpar = (size_t)(seq & 1ull), n = x.n;
+            if (act && !half)
+                for (int q = 0; q < W; ++q) {
+                    const int r = (rk + 1 + q) % W;                    // the peers first, the own slot last
+                    x.data[r][(xpar * W + rk) * n + t] = xsum;
+                }
+            __threadfence_system();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid < W) {
+                __hip_atomic_store(x.flags[tid] + (xpar * W + rk) * x.nchunks, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned long long *f = x.flags[rk] + (xpar * W + tid) * x.nchunks;
+                const unsigned long long w0 = wall_clock64();
+                bool here = v.st->xchg_timeout == 0;
+                while (here && __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (wall_clock64() - w0 > x.timeout_ticks) here = false;
+                }
+                if (!here) atomicOr(&badT, 2);
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            if (badT) continue;
+            if (act && !half) {
+                const double *mine = x.data[rk] + xpar * W * n;
+                xsum = mine[t];
+                for (int r = 1; r < W; ++r) xsum += mine[(size_t)r * n + t];
+            }
+        }
+        if (!ok || !act || half) continue;
         if (t < T) {
-            const double tot = (double)isum * tv.invInj;
+            const double tot = xsum;
             const double xi = tot - dem;                          // results.jl:58-100 (one node: imbalance = its injection)
             v.cons[t] = tot;
             v.inj[t] = xi;
@@ -164,7 +202,7 @@ __device__ DOPF_TAIL_INLINE void tail_block(const DevView *self)
             v.price[t] = ln;                                      // no lines: the nodal price is lambda
             rl = fmax(rl, fabs(ln - lam_old));
         } else {
-            const double ctot = (double)isum * tv.invCost;
+            const double ctot = xsum;
             v.cons[T] = ctot;
             v.st->total_cost = ctot;
         }
@@ -174,6 +212,7 @@ __device__ DOPF_TAIL_INLINE void tail_block(const DevView *self)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (only LDS data crosses: the stores above need not be acknowledged first)
     DOPF_TAIL_STAMP(3)
     if (tid == 0) {
+        if (badT & 2) { v.st->xchg_timeout = 1; return; }                       // a peer's part did not arrive (sticky; DOPF_E_DEVICE)
         if (badT) { v.st->tail_timeout = 1; v.st->halt = 1; return; }           // (sticky; the host reports DOPF_E_DEVICE)
         double r0 = 0.0;
         for (int q = 0; q < nth / 64; ++q) r0 = fmax(r0, wmaxT[q]);

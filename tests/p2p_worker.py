@@ -59,6 +59,15 @@ for name, case in CASES.items():
         compare(pp, n, (1, 4, 7) if name == "network" else (1, 7, 30), dict(eps=0.0, gamma=g), 1e-9)
         print("equal", name, n, flush=True)
 
+# copper plates above ran the exchange inside the tail block of the one-launch iteration; the older place —
+# inside the one-block dual kernel of the three-launch chain — stays reachable and tested
+os.environ["DOPF_NO_TAIL_XCHG"] = "1"
+kwc = dict(CASES["copper plate T96"])
+ppc = synth.synthetic_case(kwc.pop("n_gen"), kwc.pop("n_sto"), kwc.pop("T"), **kwc)
+compare(ppc, 2, (1, 7, 30), dict(eps=0.0, gamma=1.0 / (ppc.G + ppc.S)), 1e-9)
+del os.environ["DOPF_NO_TAIL_XCHG"]
+print("three-launch exchange ok", flush=True)
+
 # a consensus vector of several chunks (30 nodes, 50 lines, 24 steps: 3 121 doubles), three shards
 pp = synth.synthetic_case(240, 30, 24, N=30, L=50, seed=41, fmax_factor=0.7, fmax_min=5)
 A = pp.G + pp.S
