@@ -50,7 +50,7 @@ __device__ __forceinline__ double rcp64(double x)
 }
 
 // ------------------------------------------------------------------------------------------------
-// the tail of the iteration inside the x-update launch (DevView::tailFused; one node, no lines, single-GPU chain)
+// the tail of the iteration inside the x-update launch (DevView::tail; one node, no lines)
 // ------------------------------------------------------------------------------------------------
 //
 // Replaces, for that case, the agent loop of Result(...) (reference src/structures/results.jl:72-106), update_duals!
@@ -61,12 +61,15 @@ __device__ __forceinline__ double rcp64(double x)
 //     them and exits). The addend is (round(x * 2^k) << kAccCntBits) + 1: the upper 54 bits carry the value in fixed point
 //     (k from the problem's bounds, so that no sum can overflow; integer addition commutes, so the totals do not depend on
 //     the order in which blocks finish: bitwise reproducible), the low 10 bits count the contributions that have landed;
-//   * the launch's LAST block (dispatched after all others, so every block it waits for is running or done: no deadlock
-//     whatever the residency) polls the accumulators; thread t owns slot t and is done when the counts of its slot over
-//     the replicas add up to the number of contributing blocks — the data is its own arrival signal, one memory round
-//     trip between the last block's adds and the tail, no ticket, no fence: value and count arrive in the same atomic;
+//   * the launch's LAST block polls the accumulators (it is the ONLY block that ever waits, and no block waits for it: the
+//     others keep being dispatched into the remaining wave slots and finish on their own, whatever the dispatch order and
+//     the residency — nothing can deadlock); a lane pair owns a slot and is done when the counts of its slot over the
+//     replicas add up to the number of contributing blocks — the data is its own arrival signal, one memory round trip
+//     between the last block's adds and the tail, no ticket, no fence: value and count arrive in the same atomic;
 //   * it then runs the tail of the iteration — injection, imbalance, lambda step, price, residual, stop test: the
-//     arithmetic of k_dual_price_small's copper-plate path — and zeroes the accumulators for the next launch.
+//     arithmetic of k_dual_price_small's copper-plate path. Two accumulator sets take turns: the one a launch used is zeroed
+//     by the NEXT launch's tail block while it waits. On a context joined to a peer exchange the tail block also sums its
+//     vector over the ranks (TailView::xchg), between its own sums and the dual step.
 // The wait is bounded by wall clock (Status::tail_timeout, DOPF_E_DEVICE): the kernel always ends.
 // (First version: every block waited for its adds, took a two-level ticket, the last one drained the accumulators with
 // atomic exchanges — four dependent device-scope round trips of ~2.5 us each next to the streaming blocks: as slow as the

@@ -29,6 +29,6 @@ for wl in sys.argv[1:] or ["config2"]:
             e.iterate(400)
             best = min(best, (time.perf_counter() - t0) / 400)
         tm = e.iterate_timed(32)
-        print(f"{os.path.basename(LIB or 'product')} {wl} flags={flags} poll={os.environ.get('DOPF_TAIL_POLL','0')}: {best*1e6:.2f} us/iteration; x-update launch {1e3*(tm['gen_ms']-tm['empty_ms']):.2f} us "
+        print(f"{os.path.basename(LIB or 'product')} {wl} flags={flags}: {best*1e6:.2f} us/iteration; x-update launch {1e3*(tm['gen_ms']-tm['empty_ms']):.2f} us "
               f"(sto {1e3*(tm['sto_ms']-tm['empty_ms']):.2f}) tail_fused={tm['tail_fused']}", flush=True)
         e.close()
