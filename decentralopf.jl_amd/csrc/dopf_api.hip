@@ -411,6 +411,11 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         for (int n = 0; n < N; ++n)      // storage items: scan + warm rows; generators: items, or (one node, streaming) blocks
             max_items = std::max(max_items, (v.genRows > 0 ? v.genRows : ngib[n + 1] - ngib[n]) + 2 * (nsib[n + 1] - nsib[n]));
         v.reduceRB = std::max(1, std::min(64, (max_items + 31) / 32));
+        // Networks: nodes x timestep chunks already give hundreds of blocks, and more than one block per node means the
+        // two-level sum — an agent-scope release (a write-back of the XCD's L2) and a ticket in EVERY block. configs[3] at full
+        // size has a node with 36 partial rows: 2 blocks per node, 1 416 releases, k_reduce 38 us instead of 9. One block per
+        // node walks up to 128 rows (four passes of its 8 x 4 loads in flight) before a second one is worth its ticket.
+        if ((long long)N * ((T + 31) / 32) >= 128) v.reduceRB = std::max(1, std::min(64, (max_items + 127) / 128));
     }
 
     const size_t NT = (size_t)N * T, LT = (size_t)L * T;
