@@ -132,10 +132,13 @@ void enqueue_local(dopf_ctx *c, bool single)
     DevView v = c->v;
     v.sliceDual = slice_dual(v, single) ? 1 : 0;
     v.tail = tail_fused(c, single) ? v.tailDev : nullptr;
+    v.slackInDual = single && v.slackDualOk;
     launch_tables(v, c->main);
     const bool fork = v.nGenItems > 0 && v.nStoItems > 0 && (c->q.flags & DOPF_F_OVERLAP_AGENTS);
     if (v.fuseAgents) {
         launch_agents_fused(v, c->lc, c->main);
+    } else if (v.fuseNet) {
+        launch_net_agents(v, c->lc, c->main);
     } else if (fork) {
         hipEventRecord(c->evFork, c->main);
         hipStreamWaitEvent(c->side, c->evFork, 0);
@@ -149,7 +152,7 @@ void enqueue_local(dopf_ctx *c, bool single)
     }
     if (v.tail) return;                    // sums, dual step and stop test happened in the launch above
     launch_slack(v, c->main);
-    launch_reduce(v, c->main);
+    if (!v.slackInDual) launch_reduce(v, c->main);
 }
 
 void enqueue_apply(dopf_ctx *c, bool single, const XchgView *xd)
@@ -157,6 +160,7 @@ void enqueue_apply(dopf_ctx *c, bool single, const XchgView *xd)
     if (tail_fused(c, single)) return;
     DevView v = c->v;
     v.sliceDual = slice_dual(v, single) ? 1 : 0;
+    v.slackInDual = single && v.slackDualOk;
     launch_dual(v, c->main, xd);
 }
 
@@ -334,6 +338,11 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         if (sto_blocks > 3 * 256 || (long long)G * T > (8ll << 20)) v.fuseAgents = 0;
     }
     v.genR2 = v.genTT2 ? (v.fuseAgents ? 256 : 512) / v.genTT2 : 0;
+    v.coldInWarm = (L > 0 && v.use_warm && !getenv("DOPF_SPLIT_COLD")) ? 1 : 0;
+    // networks: generators and storages in one launch (k_net_agents) unless the storages run on a stream of their own
+    v.genTT256 = std::max(1, std::min((std::min(T, 512) + 1) / 2, 256 / v.genR));
+    v.fuseNet = (L > 0 && G > 0 && S > 0 && v.coldInWarm && !(c->q.flags & (DOPF_F_NO_FUSE | DOPF_F_OVERLAP_AGENTS)) &&
+                 !getenv("DOPF_NO_NET_FUSE")) ? 1 : 0;
 
     // sort agents by node (stable), remember the permutation
     c->gen_perm.resize(G);
@@ -380,7 +389,9 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         // ~2048 blocks fill the chip several times over; in the fused launch the generator blocks share the wave slots with
         // the storage blocks and ~1536 somewhat larger ones come out ahead (measured on config2: 25.7 -> 24.0 us)
         // (with lines ~1024 blocks: the 118-node share 93.8 -> 87.3 us per iteration, config3 at full size 204 -> 203)
-        int target_items = v.fuseAgents ? 1536 : (L > 0 ? 1024 : 2048);
+        // (networks, one launch for all agents: the generator blocks pass through the ~230 wave slots the storage blocks leave
+        // free at that kernel's register count — ~512 larger ones: the 118-node share 51.6 -> 49.5 us per iteration)
+        int target_items = v.fuseAgents ? 1536 : (L > 0 ? (v.fuseNet ? 512 : 1024) : 2048);
         if (const char *e = getenv("DOPF_GEN_TARGET_ITEMS")) target_items = std::max(1, atoi(e));     // (experiments)
         // streaming generator blocks (fused launch, one node): an item is ONE batch of loads, <= kGenStreamRows rows per lane
         const bool stream = v.fuseAgents && N == 1 && !getenv("DOPF_NO_GEN_STREAM");
@@ -501,11 +512,15 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         // networks whose dual step is the one-launch kernel (k_dual_price_t1024: <= 256 lines and nodes, consensus state beyond the
         // one-block kernel): it builds the tables too, with as many waves as find LDS scratch (<= 8) next to its own ~30 KB
         const size_t n1 = std::max(NT, LT);
-        const size_t per_wave = (4 * (size_t)v.M2 + 1) * sizeof(double), own = 25 * 1024 + ((size_t)N + 3 * (size_t)L) * sizeof(double);
+        const size_t per_wave = (4 * (size_t)v.M2 + 1) * sizeof(double), own = 25 * 1024 + (4 * (size_t)N + 3 * (size_t)L) * sizeof(double);
         int tw = 0;
         if (L > 0 && L <= 256 && N <= 256 && n1 > kSmallConsensus && !v.splitDual && !getenv("DOPF_TABLES_LAUNCH"))
             tw = (int)std::min<size_t>(8, (128 * 1024 - std::min<size_t>(own, 128 * 1024)) / per_wave);
         v.tablesInDual = tw;
+        // the same kernel forms the slack sums of its timestep (see DevView::slackInDual); DOPF_F_NO_TAIL_FUSE keeps the
+        // k_reduce launch (the chain a sharded context runs: bitwise comparisons against it)
+        v.slackDualOk = L > 0 && L <= 256 && N <= 256 && n1 > kSmallConsensus && !v.splitDual && !(q->flags & DOPF_F_NO_TAIL_FUSE) &&
+                        !getenv("DOPF_REDUCE_LAUNCH");
     }
     double *cons = nullptr;
     TRY(dev_alloc(c, &cons, NT + 2 * LT + 1));
@@ -520,7 +535,6 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     HIPTRY(hipGetLastError());
     HIPTRY(hipStreamSynchronize(c->main));
     c->host_st = st0;
-    v.coldInWarm = (L > 0 && v.use_warm && !getenv("DOPF_SPLIT_COLD")) ? 1 : 0;
     {   // the view itself in device memory (non-inlined device functions take a pointer to it)
         DevView *dv = nullptr;
         TRY(dev_alloc(c, &dv, 1, false));
@@ -623,6 +637,7 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
     if (c->comm) return fail(c, DOPF_E_INVALID, "dopf_iterate_timed drives the single-GPU chain: not on a context joined to a communicator");
     v.sliceDual = slice_dual(v, true) ? 1 : 0;
     v.tail = tail_fused(c, true) ? v.tailDev : nullptr;
+    v.slackInDual = v.slackDualOk;
     enum { E_T0, E_T1, E_G0, E_G1, E_S0, E_S1, E_K0, E_K1, E_R1, E_D1, E_X0, E_X1, E_N };
     struct Events {                                     // destroyed on every way out
         std::vector<hipEvent_t> v;
@@ -641,16 +656,17 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
         if (fork) { hipEventRecord(c->evFork, c->main); hipStreamWaitEvent(c->side, c->evFork, 0); }
         hipEventRecord(e[E_G0], c->main);
         if (v.fuseAgents) launch_agents_fused(v, c->lc, c->main);
+        else if (v.fuseNet) launch_net_agents(v, c->lc, c->main);
         else launch_gen_update(v, c->main);
         hipEventRecord(e[E_G1], c->main);
         hipEventRecord(e[E_S0], ss);
-        if (!v.fuseAgents) launch_sto_update(v, c->lc, ss);
+        if (!v.fuseAgents && !v.fuseNet) launch_sto_update(v, c->lc, ss);
         hipEventRecord(e[E_S1], ss);
         if (fork) { hipEventRecord(c->evJoin, c->side); hipStreamWaitEvent(c->main, c->evJoin, 0); }
         hipEventRecord(e[E_K0], c->main);
         if (!v.tail) launch_slack(v, c->main);
         hipEventRecord(e[E_K1], c->main);
-        if (!v.tail) launch_reduce(v, c->main);
+        if (!v.tail && !v.slackInDual) launch_reduce(v, c->main);
         hipEventRecord(e[E_R1], c->main);
         if (!v.tail) launch_dual(v, c->main);
         hipEventRecord(e[E_D1], c->main);
@@ -678,7 +694,7 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
     out->tables_ms *= inv; out->gen_ms *= inv; out->sto_ms *= inv; out->slack_ms *= inv;
     out->reduce_ms *= inv; out->dual_ms *= inv; out->iter_ms *= inv; out->empty_ms *= inv;
     out->iters = n_iters;
-    out->agents_fused = v.fuseAgents;
+    out->agents_fused = v.fuseAgents || v.fuseNet;
     out->tail_fused = v.tail ? 1 : 0;
     return DOPF_OK;
 }

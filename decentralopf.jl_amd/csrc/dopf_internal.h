@@ -76,6 +76,12 @@ struct DevView {
     int sliceDual;                  // per launch: k_reduce stops after the slice sums (level 1) and the one-block dual
                                     // kernel adds the slices itself (single-GPU iterate path, small consensus state)
     int reduceRB;                   // reduce blocks per node (two-level fixed-order sum)
+    int slackInDual;                // per launch (networks on the one-launch dual/price kernel, single-GPU chain): k_slack stores the node
+                                    // sums and the cost itself, the dual/price block of timestep t forms the slack sums of its lines from the
+                                    // PTDF rows it reads anyway — no k_reduce launch
+    int slackDualOk;                // the problem and the flags allow that
+    int genTT256;                   // networks, fused launch: column tiling of a 256-thread generator block with the same R as genR
+    int fuseNet;                    // networks: generators + storages in one launch (k_net_agents), single-GPU chain
     int fuseAgents;                 // copper plate, even T: generators + storages in one launch (k_agents, 256-thread blocks)
     int use_warm;                   // storage warm-start kernel runs first; the scan kernel serves its failures
     int max_iters;
@@ -197,6 +203,7 @@ void central_launch_scale_copy(double *dst, const double *src, double scale, siz
 // kernels_agents.hip
 void launch_gen_update(const DevView &v, hipStream_t s);
 void launch_sto_update(const DevView &v, const Launch &lc, hipStream_t s);
+void launch_net_agents(const DevView &v, const Launch &lc, hipStream_t s);
 void launch_agents_fused(const DevView &v, const Launch &lc, hipStream_t s);
 bool sto_config_supported(int T, Launch *lc);
 int debug_timeline(unsigned long long *out, int n);     // DOPF_STATS builds: per-wave stamps of the storage body

@@ -243,10 +243,95 @@ __device__ __forceinline__ void lin_coef(double w, double iw, double kap, double
 // a0 + r, a0 + r + R, ...; with T <= 512 the block sweeps a contiguous range of P (agent-major), so
 // every wave access is a dense 512-byte line set. Algorithmic traffic per update: 8 B read + 8 B write
 // of P per (g,t) + 20 B of parameters per agent (L1-broadcast to the T lanes that share an agent).
+// One item of generators at a node of a network (tables of the node's Psi): a block of BS threads, thread (r, tt) of an R x TT
+// tiling, ceil(T / TT) column passes. k_gen_update<true> runs it with 512 threads, k_net_agents (generators and storages of a
+// network in ONE launch) with 256 and the same R — the same rows meet in the same order, the sums carry the same bits.
+template <int BS>
+__device__ __forceinline__ void gen_lines_body(const DevView &v, const int item, const int TT, const int R)
+{
+    __shared__ double red[BS];
+    const Item it = v.gen_items[item];
+    const int T = v.T, N = v.N;
+    const int tid = threadIdx.x;
+    const int r = tid / TT, tt = tid - r * TT;
+    const double w = v.w_prox;
+    double cost = 0.0;
+
+    for (int tc = 0; tc < T; tc += TT) {
+        const int t = tc + tt;
+        double acc = 0.0;
+        if (r < R && t < T) {
+            const size_t at = (size_t)it.node + (size_t)N * t;
+            const int m = v.tb_m[at];
+            const double *beta = v.tb_beta + at * v.M2, *psi = v.tb_psi + at * v.M2;
+            const double *slope = v.tb_slope + at * (v.M2 + 1);
+            const double psi0 = v.tb_psi0[at];
+            const double slope0 = slope[0];
+            const double inv0 = rcp64(slope0 + w);             // (empty table: one piece for every agent of the node)
+            const bool keepd = v.keepDeltas || v.walk_any[t];      // the change is needed agent by agent only for walked slack sums
+            for (int g0 = it.a0 + r; g0 < it.a1; g0 += 4 * R) {          // four agents' rows in flight per lane
+                double mc[4], pm[4], p0[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int g = g0 + u * R < it.a1 ? g0 + u * R : g0;
+                    mc[u] = v.gen_mc[g]; pm[u] = v.gen_pmax[g]; p0[u] = v.P[(size_t)g * T + t];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int g = g0 + u * R;
+                    if (g >= it.a1) break;
+                    const size_t e = (size_t)g * T + t;
+                    double dl;
+                    if (m == 0) {
+                        dl = -(mc[u] + psi0) * inv0;
+                    } else {
+                        int lo = 0, hi = m;           // first kink with psi + w beta >= -mc
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (psi[mid] + w * beta[mid] >= -mc[u]) hi = mid; else lo = mid + 1;
+                        }
+                        const int a = lo < m ? lo : m - 1;
+                        dl = beta[a] - (mc[u] + psi[a] + w * beta[a]) * rcp64(slope[lo] + w);
+                    }
+                    const double pn = clampd(p0[u] + dl, 0.0, pm[u]);
+                    v.P[e] = pn;
+                    if (keepd) v.dltG[e] = pn - p0[u];
+                    acc += pn;
+                    cost += mc[u] * pn;
+                }
+            }
+        }
+        // fixed-order reduction over the R agent lanes that share a timestep (only LDS data crosses these barriers:
+        // __syncthreads() would also wait for the acknowledgement of the rows just stored)
+        red[tid] = acc;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (r == 0 && t < T) {
+            double sum = 0.0;
+            for (int q = 0; q < R; ++q) sum += red[q * TT + tt];
+            v.part_ginj[(size_t)item * T + t] = sum;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    // cost: butterfly inside each wave, then the waves in order — one barrier instead of one per tree level
+    __shared__ double wcost[BS / 64];
+    for (int d = 32; d > 0; d >>= 1) cost += __shfl_xor(cost, d);
+    if ((tid & 63) == 0) wcost[tid >> 6] = cost;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tid == 0) {
+        double c = 0.0;
+        for (int q = 0; q < BS / 64; ++q) c += wcost[q];
+        v.part_gcost[item] = c;
+    }
+}
+
 template <bool LINES>
 __global__ __launch_bounds__(512) void k_gen_update(DevView v)
 {
     if (v.st->halt) return;
+    if (LINES) {
+        gen_lines_body<512>(v, blockIdx.x, v.genTT, v.genR);
+        return;
+    }
     __shared__ double red[512];
     const Item it = v.gen_items[blockIdx.x];
     const int T = v.T, N = v.N, TT = v.genTT, R = v.genR;
@@ -260,59 +345,17 @@ __global__ __launch_bounds__(512) void k_gen_update(DevView v)
         const int t = tc + tt;
         double acc = 0.0;
         if (r < R && t < T) {
-            if (!LINES) {
-                // copper plate / no line touches this problem: Psi(d) = price + gamma (s + d)
-                const double shift = (v.price[it.node + N * t] + gam * v.s[t]) * inv;
+            // copper plate / no line touches this problem: Psi(d) = price + gamma (s + d)
+            const double shift = (v.price[it.node + N * t] + gam * v.s[t]) * inv;
 #pragma unroll 4
-                for (int g = it.a0 + r; g < it.a1; g += R) {
-                    const size_t e = (size_t)g * T + t;
-                    const double mc = v.gen_mc[g], pm = v.gen_pmax[g];
-                    const double p0 = v.P[e];
-                    const double pn = clampd(p0 - (mc * inv + shift), 0.0, pm);
-                    v.P[e] = pn;
-                    acc += pn;
-                    cost += mc * pn;
-                }
-            } else {
-                const size_t at = (size_t)it.node + (size_t)N * t;
-                const int m = v.tb_m[at];
-                const double *beta = v.tb_beta + at * v.M2, *psi = v.tb_psi + at * v.M2;
-                const double *slope = v.tb_slope + at * (v.M2 + 1);
-                const double psi0 = v.tb_psi0[at];
-                const double slope0 = slope[0];
-                const double inv0 = rcp64(slope0 + w);             // (empty table: one piece for every agent of the node)
-                const bool keepd = v.keepDeltas || v.walk_any[t];      // the change is needed agent by agent only for walked slack sums
-                for (int g0 = it.a0 + r; g0 < it.a1; g0 += 4 * R) {          // four agents' rows in flight per lane
-                    double mc[4], pm[4], p0[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int g = g0 + u * R < it.a1 ? g0 + u * R : g0;
-                        mc[u] = v.gen_mc[g]; pm[u] = v.gen_pmax[g]; p0[u] = v.P[(size_t)g * T + t];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int g = g0 + u * R;
-                        if (g >= it.a1) break;
-                        const size_t e = (size_t)g * T + t;
-                        double dl;
-                        if (m == 0) {
-                            dl = -(mc[u] + psi0) * inv0;
-                        } else {
-                            int lo = 0, hi = m;           // first kink with psi + w beta >= -mc
-                            while (lo < hi) {
-                                const int mid = (lo + hi) >> 1;
-                                if (psi[mid] + w * beta[mid] >= -mc[u]) hi = mid; else lo = mid + 1;
-                            }
-                            const int a = lo < m ? lo : m - 1;
-                            dl = beta[a] - (mc[u] + psi[a] + w * beta[a]) * rcp64(slope[lo] + w);
-                        }
-                        const double pn = clampd(p0[u] + dl, 0.0, pm[u]);
-                        v.P[e] = pn;
-                        if (keepd) v.dltG[e] = pn - p0[u];
-                        acc += pn;
-                        cost += mc[u] * pn;
-                    }
-                }
+            for (int g = it.a0 + r; g < it.a1; g += R) {
+                const size_t e = (size_t)g * T + t;
+                const double mc = v.gen_mc[g], pm = v.gen_pmax[g];
+                const double p0 = v.P[e];
+                const double pn = clampd(p0 - (mc * inv + shift), 0.0, pm);
+                v.P[e] = pn;
+                acc += pn;
+                cost += mc * pn;
             }
         }
         // fixed-order reduction over the R agent lanes that share a timestep (only LDS data crosses these barriers:
@@ -1994,6 +2037,29 @@ __global__ __launch_bounds__(256, DOPF_WARM_WAVES) void k_sto_warm(DevView v)
     }
 }
 
+// Networks, single-GPU chain: generators and storages in ONE launch — the storage items first (a block lives for the whole
+// launch: a chain of dependent round trips), the generator items behind them in 256-thread blocks that pass through the
+// wave slots the storages leave free. Alone, either launch is a few hundred short blocks bound by its own latency chain
+// (configs[3]'s share: 12 + 13 us and a kernel boundary); together they overlap.
+template <int LPS, int NCH>
+__global__ __launch_bounds__(256, DOPF_WARM_WAVES) void k_net_agents(DevView v)
+{
+    const int nS = v.nStoItems;
+    if ((int)blockIdx.x >= nS) {
+        if (v.st->halt) return;
+        gen_lines_body<256>(v, blockIdx.x - nS, v.genTT256, v.genR);
+        return;
+    }
+    const int left = sto_warm_body<LPS, NCH, true>(v, blockIdx.x, v.st->halt);         // ends on a __syncthreads
+    if (left < 0) return;                                                               // halted
+    if (left == 0) {                         // (what the scan body writes when there is nothing for it)
+        for (int t = threadIdx.x; t < v.T; t += 256) v.part_sinj[(size_t)blockIdx.x * v.T + t] = 0.0;
+        if (threadIdx.x == 0) v.part_scost[blockIdx.x] = 0.0;
+    } else {
+        sto_cold_lines_call<LPS, NCH>(v.self, blockIdx.x, left);
+    }
+}
+
 // Warm start and, in the same block, the cold scan for what it left over: one launch for the storages of the big
 // copper-plate grids (the separate k_sto_update launch mostly found nothing to do).
 template <int LPS, int NCH, bool LINES, bool TAIL, bool FULLT>
@@ -2111,6 +2177,17 @@ static void launch_agents_t(const DevView &v, hipStream_t s)
 void launch_agents_fused(const DevView &v, const Launch &lc, hipStream_t s)
 {
 #define DOPF_CASE(LPS_, NCH_) if (lc.stoLPS == LPS_ && lc.stoNCH == NCH_) { launch_agents_t<LPS_, NCH_>(v, s); return; }
+    DOPF_CASE(8, 1) DOPF_CASE(8, 2) DOPF_CASE(8, 3)
+    DOPF_CASE(16, 3)
+    DOPF_CASE(32, 3)
+    DOPF_CASE(64, 3)
+#undef DOPF_CASE
+}
+
+void launch_net_agents(const DevView &v, const Launch &lc, hipStream_t s)
+{
+    const dim3 grid(v.nStoItems + v.nGenItems);
+#define DOPF_CASE(LPS_, NCH_) if (lc.stoLPS == LPS_ && lc.stoNCH == NCH_) { hipLaunchKernelGGL((k_net_agents<LPS_, NCH_>), grid, dim3(256), 0, s, v); return; }
     DOPF_CASE(8, 1) DOPF_CASE(8, 2) DOPF_CASE(8, 3)
     DOPF_CASE(16, 3)
     DOPF_CASE(32, 3)

@@ -244,6 +244,40 @@ __device__ __forceinline__ double walk_sum(const DevView &v, const double *dtile
     return acc;
 }
 
+// lane r of eight: rows i0 + r, i0 + r + 8, ... (below i1) of a node's partial rows at timestep t — generator items, then the
+// storage items' scan partials, then their warm-start partials. Four loads in flight, no branch between them (one select
+// on the address); the grouping is fixed (k_reduce level 1, and k_slack when it stores the node sums itself: same bits)
+__device__ __forceinline__ double rows_sum(const DevView &v, int g0, int ngi, int s0, int nsi, int i0, int i1, int r, int t)
+{
+    constexpr int R = 8;
+    const int T = v.T;
+    double acc = 0.0;
+    for (int i = i0 + r; i < i1; i += 4 * R) {
+        double x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = i + u * R;
+            const int jj = j < i1 ? j : i0;                               // in range: always a valid row
+            const double *row = jj < ngi ? v.part_ginj + (size_t)(g0 + jj) * T
+                              : (jj < ngi + nsi ? v.part_sinj + (size_t)(s0 + jj - ngi) * T
+                                                : v.part_sinj_w + (size_t)(s0 + jj - ngi - nsi) * T);
+            const double val = row[t];
+            x[u] = j < i1 ? val : 0.0;
+        }
+        acc += (x[0] + x[1]) + (x[2] + x[3]);
+    }
+    return acc;
+}
+
+// total cost of the iteration from the items' partials, by one block of 256 (fixed order)
+__device__ __forceinline__ double cost_rows_sum(const DevView &v, int c0, int c1, int ngr, double *red)
+{
+    double c = 0.0;
+    for (int i = c0 + (int)threadIdx.x; i < c1; i += 256)
+        c += i < ngr ? v.part_gcost[i] : v.part_scost[i - ngr] + v.part_scost_w[i - ngr];
+    return block_sum256(c, red);
+}
+
 __global__ __launch_bounds__(256) void k_slack(DevView v, const int cap)
 {
     if (v.st->halt) return;
@@ -260,21 +294,34 @@ __global__ __launch_bounds__(256) void k_slack(DevView v, const int cap)
     const double W = v.node_win[n];
     const int nt = min(TS, T - t0), np = L * nt;
     {   // the change of the node's injection in this iteration = new minus previous sum of its items' partials (read along
-        // t: coalesced); the new sums become "previous" for the next iteration — this block owns these (item, t) entries
+        // t: coalesced; four rows in flight per lane, added in row order); the new sums become "previous" for the next
+        // iteration — this block owns these (item, t) entries
         const int r = tid >> 5, tt = tid & 31, t = t0 + tt;
         __shared__ double redn[256];
+        const int g0 = v.node_gitem_beg[n], g1 = v.node_gitem_beg[n + 1], s0 = v.node_sitem_beg[n], s1 = v.node_sitem_beg[n + 1];
         double sd = 0.0;
         if (t < T) {
-            const int g0 = v.node_gitem_beg[n], g1 = v.node_gitem_beg[n + 1], s0 = v.node_sitem_beg[n], s1 = v.node_sitem_beg[n + 1];
-            for (int j = g0 + r; j < g1; j += 8) {
-                const double now = v.part_ginj[(size_t)j * T + t];
-                sd += now - v.prev_ginj[(size_t)j * T + t];
-                v.prev_ginj[(size_t)j * T + t] = now;
+            for (int j0 = g0 + r; j0 < g1; j0 += 32) {
+                double now[4], was[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + 8 * u < g1 ? j0 + 8 * u : j0;
+                    now[u] = v.part_ginj[(size_t)j * T + t]; was[u] = v.prev_ginj[(size_t)j * T + t];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + 8 * u < g1) { sd += now[u] - was[u]; v.prev_ginj[(size_t)(j0 + 8 * u) * T + t] = now[u]; }
             }
-            for (int j = s0 + r; j < s1; j += 8) {
-                const double now = v.part_sinj[(size_t)j * T + t] + v.part_sinj_w[(size_t)j * T + t];
-                sd += now - v.prev_sinj[(size_t)j * T + t];
-                v.prev_sinj[(size_t)j * T + t] = now;
+            for (int j0 = s0 + r; j0 < s1; j0 += 32) {
+                double now[4], was[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + 8 * u < s1 ? j0 + 8 * u : j0;
+                    now[u] = v.part_sinj[(size_t)j * T + t] + v.part_sinj_w[(size_t)j * T + t]; was[u] = v.prev_sinj[(size_t)j * T + t];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + 8 * u < s1) { sd += now[u] - was[u]; v.prev_sinj[(size_t)(j0 + 8 * u) * T + t] = now[u]; }
             }
         }
         redn[tid] = sd;
@@ -283,6 +330,26 @@ __global__ __launch_bounds__(256) void k_slack(DevView v, const int cap)
             double sum = 0.0;
             for (int q = 0; q < 8; ++q) sum += redn[q * 32 + tt];
             v.node_dsum[n + (size_t)N * t] = sum;
+        }
+        if (v.slackInDual) {
+            // no k_reduce launch behind this one: the node's sum and the cost leave from here, with k_reduce's arithmetic
+            // (one slice per node) — the rows are in this CU's cache from the loop above
+            const int ngi = g1 - g0, nsi = s1 - s0;
+            const double acc = t < T ? rows_sum(v, g0, ngi, s0, nsi, 0, ngi + 2 * nsi, r, t) : 0.0;
+            __syncthreads();
+            redn[tid] = acc;
+            __syncthreads();
+            if (r == 0 && t < T) {
+                double sum = 0.0;
+                for (int q = 0; q < 8; ++q) sum += redn[q * 32 + tt];
+                v.cons[n + (size_t)N * t] = sum;
+            }
+            if (blockIdx.x == 0) {
+                __syncthreads();
+                const int ngr = v.genRows > 0 ? v.genRows : v.nGenItems;
+                const double c = cost_rows_sum(v, 0, ngr + v.nStoItems, ngr, redn);
+                if (tid == 0) v.cons[(size_t)N * T + 2 * (size_t)L * T] = c;
+            }
         }
     }
     {   // usually no (line, timestep) of this chunk has a switch point within anybody's reach: k_reduce takes the closed forms
@@ -353,6 +420,86 @@ __device__ __forceinline__ bool slack_needs_cases(double g, double w2, double in
     return !(uOk && kOk);
 }
 
+// closed form of a part's contribution when every agent of every node has the slack active (offset a > 0): the two kernels
+// that form slack sums must round identically — no contraction left to the compiler
+__device__ __forceinline__ double slack_sum_plain(int which, double cnt, double a, double w2inv, double dot)
+{
+#pragma clang fp contract(off)
+    const double x = cnt * a, y = w2inv * dot;
+    return which ? x + y : x - y;
+}
+
+// The part [nbeg, nend) of the nodes' contributions to the slack sum (which: 0 = U, 1 = K) of a line whose switch point lies
+// inside some node's window. Pass 1, the part's nodes in order: closed forms are added at once, the nodes k_slack had to walk
+// are remembered in a bit mask (a load whose address hangs on this arithmetic would put two dependent memory round trips
+// into every batch); pass 2 fetches the walked sums, eight in flight. Both orders are fixed. (k_reduce, and the one-launch
+// dual/price kernel when it forms the slack sums itself: same bits.)
+__device__ __forceinline__ double slack_sum_cases(const DevView &v, int which, int l, int t, int nbeg, int nend, const double *sdL,
+                                                  const double *winL, const double *naL, double f, double F, double cu, double ck)
+{
+#pragma clang fp contract(off)
+    const int N = v.N, L = v.L;
+    const double *src = which ? v.part_K : v.part_U;
+    const double w2 = 2.0 * v.w_flow, g = v.gamma, inv = 1.0 / (w2 + g);
+    constexpr int MW = 4;                              // mask words: a part of up to 128 nodes (more: fetched inline)
+    unsigned wm[MW];
+#pragma unroll
+    for (int q = 0; q < MW; ++q) wm[q] = 0u;
+    double sum = 0.0;
+    for (int n0 = nbeg; n0 < nend; n0 += 8) {
+        double h[8], x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) h[u] = v.ptdf[l + (size_t)L * (n0 + u < nend ? n0 + u : nend - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int n = n0 + u < nend ? n0 + u : nend - 1;
+            const SlackCase c = slack_case(g, w2, inv, h[u], f, F, cu, ck, winL[n]);
+            const double a = which ? c.aK : c.aU;
+            const bool live = n0 + u < nend, all_on = a - c.reach >= 0.0, walked = live && !all_on && a + c.reach > 0.0;
+            x[u] = (live && all_on) ? (which ? naL[n] * c.aK + c.kap * sdL[n] : naL[n] * c.aU - c.kap * sdL[n]) : 0.0;
+            if (walked) {
+                const int k = n - nbeg;
+                if (k < 32 * MW) {
+#pragma unroll
+                    for (int q = 0; q < MW; ++q)
+                        if (q == (k >> 5)) wm[q] |= 1u << (k & 31);
+                } else {
+                    x[u] = src[((size_t)n + (size_t)N * t) * L + l];
+                }
+            }
+        }
+        sum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+    }
+#pragma unroll
+    for (int q = 0; q < MW; ++q) {
+        unsigned m = wm[q];
+        while (m) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                x[u] = 0.0;
+                if (m) {
+                    const int n = nbeg + 32 * q + __builtin_ctz(m);
+                    m &= m - 1u;
+                    x[u] = src[((size_t)n + (size_t)N * t) * L + l];
+                }
+            }
+            sum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+        }
+    }
+    return sum;
+}
+
+// (the one-launch dual/price kernel's rare case, kept out of line: its registers are not that kernel's problem)
+__device__ __attribute__((noinline)) void slack_sum_cases_both(const DevView *self, int l, int t, int nbeg, int nend, const double *sdL,
+                                                               const double *winL, const double *naL, double f, double F, double cu,
+                                                               double ck, double *pu, double *pk)
+{
+    const DevView &v = *self;
+    *pu = slack_sum_cases(v, 0, l, t, nbeg, nend, sdL, winL, naL, f, F, cu, ck);
+    *pk = slack_sum_cases(v, 1, l, t, nbeg, nend, sdL, winL, naL, f, F, cu, ck);
+}
+
 // ------------------------------------------------------------------------------------------------
 // reduce: RB blocks per node sum slices of the node's item partials (level 1); the block that
 // finishes last for a node adds the RB slice sums in slice order (level 2) — the order of every
@@ -383,24 +530,7 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
         const int ni = ngi + 2 * nsi;
         const int per = (ni + RB - 1) / RB;
         const int i0 = rb * per, i1 = min(ni, i0 + per);
-        double acc = 0.0;
-        if (t < T) {
-            // four loads in flight per lane, no branch between them (one select on the address); fixed grouping
-            for (int i = i0 + r; i < i1; i += 4 * R) {
-                double x[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = i + u * R;
-                    const int jj = j < i1 ? j : i0;                               // in range: always a valid row
-                    const double *row = jj < ngi ? v.part_ginj + (size_t)(g0 + jj) * T
-                                      : (jj < ngi + nsi ? v.part_sinj + (size_t)(s0 + jj - ngi) * T
-                                                        : v.part_sinj_w + (size_t)(s0 + jj - ngi - nsi) * T);
-                    const double val = row[t];
-                    x[u] = j < i1 ? val : 0.0;
-                }
-                acc += (x[0] + x[1]) + (x[2] + x[3]);
-            }
-        }
+        const double acc = t < T ? rows_sum(v, g0, ngi, s0, nsi, i0, i1, r, t) : 0.0;
         if (halt) return;                                   // (uniform)
         red[tid] = acc;
         __syncthreads();
@@ -416,10 +546,7 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
             const int ngr = v.genRows > 0 ? v.genRows : v.nGenItems;
             const int nc = ngr + v.nStoItems, cper = (nc + RB - 1) / RB;
             const int c0 = rb * cper, c1 = min(nc, c0 + cper);
-            double c = 0.0;
-            for (int i = c0 + tid; i < c1; i += 256)
-                c += i < ngr ? v.part_gcost[i] : v.part_scost[i - ngr] + v.part_scost_w[i - ngr];
-            c = block_sum256(c, red);
+            const double c = cost_rows_sum(v, c0, c1, ngr, red);
             if (tid == 0) {
                 if (direct) v.cons[(size_t)N * T + 2 * (size_t)L * T] = c;
                 else v.part2_cost[rb] = c;
@@ -490,7 +617,6 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
         __syncthreads();
         const int pr = tid >> 6, ll = tid & 63, l = lb * 64 + ll;
         const int Nc = (((N + 3) / 4) + 7) & ~7, nbeg = pr * Nc, nend = min(N, nbeg + Nc);
-        const double *src = which ? v.part_K : v.part_U;
         const double w2 = 2.0 * v.w_flow, g = v.gamma, inv = 1.0 / (w2 + g);
         double partial = 0.0;
         if (l < L && nbeg < nend) {
@@ -508,61 +634,12 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
                         for (int u = 0; u < kFlight; ++u) h[u] = n0 + u < nend ? v.ptdf[l + (size_t)L * (n0 + u)] : 0.0;
 #pragma unroll
                         for (int u = 0; u < kFlight; ++u)
-                            if (n0 + u < nend) { dot += h[u] * sdL[n0 + u]; cnt += naL[n0 + u]; }
+                            if (n0 + u < nend) { dot = fma(h[u], sdL[n0 + u], dot); cnt += naL[n0 + u]; }
                     }
-                    partial = which ? cnt * a + (w2 * inv) * dot : cnt * a - (w2 * inv) * dot;
+                    partial = slack_sum_plain(which, cnt, a, w2 * inv, dot);
                 }
             } else {
-                // pass 1, the part's nodes in order: closed forms are added at once, the nodes k_slack had to walk are
-                // remembered in a bit mask (a load whose address hangs on this arithmetic would put two dependent memory
-                // round trips into every batch); pass 2 fetches the walked sums, eight in flight. Both orders are fixed.
-                constexpr int MW = 4;                              // mask words: a part of up to 128 nodes (more: fetched inline)
-                unsigned wm[MW];
-#pragma unroll
-                for (int q = 0; q < MW; ++q) wm[q] = 0u;
-                double sum = 0.0;
-                for (int n0 = nbeg; n0 < nend; n0 += 8) {
-                    double h[8], x[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) h[u] = v.ptdf[l + (size_t)L * (n0 + u < nend ? n0 + u : nend - 1)];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int n = n0 + u < nend ? n0 + u : nend - 1;
-                        const SlackCase c = slack_case(g, w2, inv, h[u], f, F, cu, ck, winL[n]);
-                        const double a = which ? c.aK : c.aU;
-                        const bool live = n0 + u < nend, all_on = a - c.reach >= 0.0, walked = live && !all_on && a + c.reach > 0.0;
-                        x[u] = (live && all_on) ? (which ? naL[n] * c.aK + c.kap * sdL[n] : naL[n] * c.aU - c.kap * sdL[n]) : 0.0;
-                        if (walked) {
-                            const int k = n - nbeg;
-                            if (k < 32 * MW) {
-#pragma unroll
-                                for (int q = 0; q < MW; ++q)
-                                    if (q == (k >> 5)) wm[q] |= 1u << (k & 31);
-                            } else {
-                                x[u] = src[((size_t)n + (size_t)N * t) * L + l];
-                            }
-                        }
-                    }
-                    sum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-                }
-#pragma unroll
-                for (int q = 0; q < MW; ++q) {
-                    unsigned m = wm[q];
-                    while (m) {
-                        double x[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            x[u] = 0.0;
-                            if (m) {
-                                const int n = nbeg + 32 * q + __builtin_ctz(m);
-                                m &= m - 1u;
-                                x[u] = src[((size_t)n + (size_t)N * t) * L + l];
-                            }
-                        }
-                        sum += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-                    }
-                }
-                partial = sum;
+                partial = slack_sum_cases(v, which, l, t, nbeg, nend, sdL, winL, naL, f, F, cu, ck);
             }
         }
         pred[tid] = partial;
@@ -1109,28 +1186,49 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
     const double g = v.gamma, w2 = 2.0 * v.w_flow, inv = 1.0 / (w2 + g);
 
     // ---- dual half: thread (node part pl, line l) --------------------------------------------------------------
+    // sid: the slack sums of this timestep's lines are formed HERE, from the PTDF rows the flows need anyway and the nodes'
+    // injection changes (k_slack) — with k_reduce's arithmetic, part by part — instead of by a launch in between
+    const bool sid = UPDATE && v.slackInDual;
+    double *sdL = sh + N + 3 * L + (size_t)v.tablesInDual * (4 * v.M2 + 1), *winL = sdL + N, *naL = winL + N;
     const int pl = tid >> 8, l = tid & 255;
     const bool lt = pl == 0 && l < L;
     const size_t i = (size_t)(l < L ? l : 0) + (size_t)L * t;
-    double f_old = 0.0, aU_old = 0.0, aK_old = 0.0, mo = 0.0, ro = 0.0, F = 0.0, sU = 0.0, sK = 0.0, reach = 0.0;
-    if (lt) {                                    // (in flight while the flows are formed)
-        f_old = v.flow[i]; aU_old = v.avgU[i]; aK_old = v.avgK[i]; mo = v.mu[i]; ro = v.rho[i];
-        F = v.fmax[l]; sU = cU[i]; sK = cK[i]; reach = v.line_reach[l];
+    const int Nc = (((N + 3) / 4) + 7) & ~7, nbeg = pl * Nc, nend = min(N, nbeg + Nc);
+    double f_old = 0.0, aU_old = 0.0, aK_old = 0.0, mo = 0.0, ro = 0.0, F = 0.0, sU = 0.0, sK = 0.0, reach = 0.0, cntp = 0.0;
+    int wf = 0;
+    if (lt || (sid && l < L)) {                  // (in flight while the flows are formed)
+        f_old = v.flow[i]; aU_old = v.avgU[i]; aK_old = v.avgK[i]; F = v.fmax[l];
+    }
+    if (lt) {
+        mo = v.mu[i]; ro = v.rho[i]; reach = v.line_reach[l];
+        if (!sid) { sU = cU[i]; sK = cK[i]; }
+    }
+    if (sid && l < L) {
+        wf = v.walk_flag[i];
+        if (nbeg < nend)                         // agents at the part's nodes
+            cntp = (double)((v.node_gen_beg[nend] - v.node_gen_beg[nbeg]) + (v.node_sto_beg[nend] - v.node_sto_beg[nbeg]));
     }
     const double lam_old = v.lam[t], s_old = v.s[t];
-    const int Nc = (((N + 3) / 4) + 7) & ~7, nbeg = pl * Nc, nend = min(N, nbeg + Nc);
     double x = 0.0;
     if (tid < N) {
         x = cinj[tid + (size_t)N * t] - v.demand[tid + (size_t)N * t];       // results.jl:58-100
         q[tid] = x;
+        if (sid) sdL[tid] = v.node_dsum[tid + (size_t)N * t];
     }
     {   // imbalance: butterfly inside each of the (at most four) waves that hold nodes, waves in order
         double ps = x;
         for (int d = 32; d > 0; d >>= 1) ps += __shfl_xor(ps, d);
         if (lane == 0 && tid < 256) wsum[tid >> 6] = ps;
     }
-    __syncthreads();
+    const int anyWalk = __syncthreads_or(wf);
     if (halt) return;                                    // (uniform)
+    if (anyWalk) {                                       // (rare, uniform) a line of t has its switch point inside a node's window
+        if (tid < N) {
+            winL[tid] = v.node_win[tid];
+            naL[tid] = (double)((v.node_gen_beg[tid + 1] - v.node_gen_beg[tid]) + (v.node_sto_beg[tid + 1] - v.node_sto_beg[tid]));
+        }
+        __syncthreads();
+    }
     if (tid < N) v.inj[tid + (size_t)N * t] = x;
     const double sum = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
     const double ln = UPDATE ? lam_old + g * sum : lam_old;                     // update_duals.jl:8-13
@@ -1138,7 +1236,7 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         if (UPDATE) { v.s_used[t] = s_old; v.lam_used[t] = lam_old; v.lam[t] = ln; }
         v.s[t] = sum;
     }
-    double f = 0.0;
+    double f = 0.0, ds = 0.0;
     if (l < L)
         for (int n0 = nbeg; n0 < nend; n0 += kFlight) {                        // kFlight rows of ptdf in flight
             double h[kFlight];
@@ -1146,13 +1244,36 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
             for (int u = 0; u < kFlight; ++u) h[u] = n0 + u < nend ? v.ptdf[l + (size_t)L * (n0 + u)] : 0.0;
 #pragma unroll
             for (int u = 0; u < kFlight; ++u) f += h[u] * (n0 + u < nend ? q[n0 + u] : 0.0);
+            if (sid) {
+#pragma unroll
+                for (int u = 0; u < kFlight; ++u)
+                    if (n0 + u < nend) ds = fma(h[u], sdL[n0 + u], ds);
+            }
         }
     red[0][tid] = f;
+    if (sid) {
+        double pu = 0.0, pk = 0.0;
+        if (l < L && nbeg < nend) {
+            if (!wf) {
+                const SlackCase c0 = slack_case(g, w2, inv, 0.0, f_old, F, aU_old, aK_old, 0.0);
+                if (c0.aU > 0.0) pu = slack_sum_plain(0, cntp, c0.aU, w2 * inv, ds);
+                if (c0.aK > 0.0) pk = slack_sum_plain(1, cntp, c0.aK, w2 * inv, ds);
+            } else {
+                slack_sum_cases_both(v.self, l, t, nbeg, nend, sdL, winL, naL, f_old, F, aU_old, aK_old, &pu, &pk);
+            }
+        }
+        red[1][tid] = pu; red[2][tid] = pk;
+    }
     __syncthreads();
     double rm = 0.0, rr = 0.0;
     int flag = 0, nzl = 0;
     if (lt) {
         f = ((red[0][l] + red[0][256 + l]) + red[0][512 + l]) + red[0][768 + l];
+        if (sid) {                               // (stored: dopf_get_consensus, and what a later k_reduce-chain call would have left)
+            sU = ((red[1][l] + red[1][256 + l]) + red[1][512 + l]) + red[1][768 + l];
+            sK = ((red[2][l] + red[2][256 + l]) + red[2][512 + l]) + red[2][768 + l];
+            v.cons[NT + i] = sU; v.cons[NT + LT + i] = sK;
+        }
         double aU = aU_old, aK = aK_old, mn = mo, rn = ro;
         if (UPDATE) {
             v.flow_used[i] = f_old; v.avgU_used[i] = aU_old; v.avgK_used[i] = aK_old;
@@ -1467,7 +1588,7 @@ __global__ __launch_bounds__(256) void k_dual_price_small(DevView v, XchgView x)
 // dynamic LDS of k_dual_price_t1024: its own vectors, plus table scratch for tablesInDual waves
 static size_t t1024_lds(const DevView &v)
 {
-    const size_t bytes = ((size_t)v.N + 3 * (size_t)v.L + (size_t)v.tablesInDual * (4 * (size_t)v.M2 + 1)) * sizeof(double);
+    const size_t bytes = (4 * (size_t)v.N + 3 * (size_t)v.L + (size_t)v.tablesInDual * (4 * (size_t)v.M2 + 1)) * sizeof(double);
     static bool raised = false;
     if (bytes > 48 * 1024 && !raised) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_dual_price_t1024<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);

@@ -357,6 +357,44 @@ def test_hip_tail_in_the_launch_matches_the_three_launch_chain(hip_api, name, ma
     assert abs(c.get_consensus()[4] - d.get_consensus()[4]) <= 1e-9 * abs(d.get_consensus()[4])
 
 
+SLACK_IN_DUAL = [
+    ("30 nodes / 45 lines, limits binding", lambda: synth.synthetic_case(500, 50, 168, N=30, L=45, seed=11, fmax_factor=1.0, fmax_min=20), 0.3),
+    ("30 nodes / 45 lines, literal flow weight", lambda: synth.synthetic_case(500, 50, 168, N=30, L=45, seed=12), None),
+    ("118 nodes / 186 lines (2 % of configs[3])", lambda: synth.baseline_config(3, scale=0.02), 0.3),
+    ("118 nodes / 186 lines, literal flow weight", lambda: synth.baseline_config(3, scale=0.02), None),
+]
+
+
+@pytest.mark.parametrize("name,make,wf", SLACK_IN_DUAL, ids=[t[0] for t in SLACK_IN_DUAL])
+def test_hip_slack_sums_in_the_dual_launch_are_bit_identical(hip_api, monkeypatch, name, make, wf):
+    """Networks on the one-launch dual/price kernel (single-GPU chain): generators and storages in one launch (256-thread
+    generator blocks, k_net_agents), the node sums leave from k_slack and the slack sums of timestep t are formed by the dual
+    block of t (no k_reduce launch) — against the five-launch chain (DOPF_F_NO_TAIL_FUSE | DOPF_F_NO_FUSE: 512-thread
+    generator kernel, storage kernel, k_slack, k_reduce, dual): every array the C ABI exposes is bit-identical at every step,
+    through the cold start (lines whose switch point lies inside a node's window: the agent-by-agent sums) and after.
+    (Same generator items on both sides: the one-launch form would take half as many, twice as large.)"""
+    monkeypatch.setenv("DOPF_GEN_TARGET_ITEMS", "512")
+    pp = make()
+    A = pp.G + pp.S
+    kw = dict(eps=0.0, gamma=1.0 / A)
+    if wf is not None:
+        kw["w_flow"] = wf / A
+    a = make_engine(hip_api, pp, **kw)
+    b = make_engine(hip_api, pp, flags=_capi.F_NO_TAIL_FUSE | _capi.F_NO_FUSE, **kw)
+    assert a.iterate_timed(1)["agents_fused"] == 1 and b.iterate_timed(1)["agents_fused"] == 0
+    for n in (1, 3, 20, 100):
+        a.iterate(n)
+        b.iterate(n)
+        sa, sb = state_of(a), state_of(b)
+        for k in sa:
+            if k == "cost":              # (a block's cost is a butterfly per wave, then the waves in order: 4 waves against 8)
+                assert abs(sa[k][0] - sb[k][0]) <= 1e-13 * abs(sb[k][0])
+            elif sa[k].size:
+                assert np.array_equal(sa[k], sb[k]), (n, k, float(np.abs(sa[k] - sb[k]).max()))
+    assert a.solver_failures() == 0 and b.solver_failures() == 0
+    assert np.abs(sa["avg_U"]).max() > 0 or np.abs(sa["avg_K"]).max() > 0 or wf is not None
+
+
 def test_hip_row_skipping_is_bit_identical(hip_api):
     """1M agents x 24: the generator kernel that skips rows of P parked on a bound against the full sweep."""
     pp = synth.baseline_config(4)
