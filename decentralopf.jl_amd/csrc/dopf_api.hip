@@ -492,7 +492,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     TRY(dev_alloc(c, &v.part_ginj, (size_t)v.nGenItems * T)); TRY(dev_alloc(c, &v.part_gcost, v.nGenItems));
     TRY(dev_alloc(c, &v.part_sinj, (size_t)v.nStoItems * T)); TRY(dev_alloc(c, &v.part_scost, v.nStoItems));
     TRY(dev_alloc(c, &v.part_sinj_w, (size_t)v.nStoItems * T)); TRY(dev_alloc(c, &v.part_scost_w, v.nStoItems));
-    if (L > 0) { TRY(dev_alloc(c, &v.prev_ginj, (size_t)v.nGenItems * T)); TRY(dev_alloc(c, &v.prev_sinj, (size_t)v.nStoItems * T)); }
+    if (L > 0) TRY(dev_alloc(c, &v.prev_node, NT));
     TRY(dev_alloc(c, &v.nu_prev, (size_t)S * T)); TRY(dev_alloc(c, &v.nu_valid, S)); TRY(dev_alloc(c, &v.sto_fail, S));
     TRY(dev_alloc(c, &v.item_fail, v.nStoItems));
     TRY(dev_alloc(c, &v.part2, (size_t)N * v.reduceRB * T)); TRY(dev_alloc(c, &v.part2_cost, v.reduceRB));

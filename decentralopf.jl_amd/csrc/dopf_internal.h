@@ -116,8 +116,7 @@ struct DevView {
     int *nu_valid, *sto_fail, *item_fail;           // [s], [s], [item] (= storages of the item the warm start left over)
     double *part_U, *part_K;                        // [(n + N*t)*L + l]: only the entries k_slack had to walk agent by agent
     double *node_dsum;                              // [n + N*t] change of the node's injection in this iteration (L > 0)
-    double *prev_ginj, *prev_sinj;                  // [item*T + t] the items' injection sums of the previous iteration (L > 0): the change of a
-                                                    // node's injection, which the closed-form slack sums need, is new - previous over its items
+    double *prev_node;                              // [n + N*t] the node's (this rank's agents') injection sum of the previous iteration (L > 0)
     const double *line_reach;                       // [l] max over nodes of |kap| W_n: beyond it no agent of any node can flip the line's slack
     int *tab_skip;                                  // [t] the price kernel has written the (empty) tables of timestep t
     int *walk_flag, *walk_any;                      // [l + L*t], [t]: the slack sums of (l,t) need the per-node cases (set by the dual step)

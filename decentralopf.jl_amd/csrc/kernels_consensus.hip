@@ -293,63 +293,26 @@ __global__ __launch_bounds__(256) void k_slack(DevView v, const int cap)
     const double w2 = 2.0 * v.w_flow, g = v.gamma, inv = 1.0 / (w2 + g);
     const double W = v.node_win[n];
     const int nt = min(TS, T - t0), np = L * nt;
-    {   // the change of the node's injection in this iteration = new minus previous sum of its items' partials (read along
-        // t: coalesced; four rows in flight per lane, added in row order); the new sums become "previous" for the next
-        // iteration — this block owns these (item, t) entries
+    {   // the node's injection sum of this iteration (its items' partial rows, read along t: coalesced, k_reduce's order and
+        // bits) and its change against the previous iteration's — what the closed-form slack sums need
         const int r = tid >> 5, tt = tid & 31, t = t0 + tt;
         __shared__ double redn[256];
-        const int g0 = v.node_gitem_beg[n], g1 = v.node_gitem_beg[n + 1], s0 = v.node_sitem_beg[n], s1 = v.node_sitem_beg[n + 1];
-        double sd = 0.0;
-        if (t < T) {
-            for (int j0 = g0 + r; j0 < g1; j0 += 32) {
-                double now[4], was[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = j0 + 8 * u < g1 ? j0 + 8 * u : j0;
-                    now[u] = v.part_ginj[(size_t)j * T + t]; was[u] = v.prev_ginj[(size_t)j * T + t];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (j0 + 8 * u < g1) { sd += now[u] - was[u]; v.prev_ginj[(size_t)(j0 + 8 * u) * T + t] = now[u]; }
-            }
-            for (int j0 = s0 + r; j0 < s1; j0 += 32) {
-                double now[4], was[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = j0 + 8 * u < s1 ? j0 + 8 * u : j0;
-                    now[u] = v.part_sinj[(size_t)j * T + t] + v.part_sinj_w[(size_t)j * T + t]; was[u] = v.prev_sinj[(size_t)j * T + t];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (j0 + 8 * u < s1) { sd += now[u] - was[u]; v.prev_sinj[(size_t)(j0 + 8 * u) * T + t] = now[u]; }
-            }
-        }
-        redn[tid] = sd;
+        const size_t at = (size_t)n + (size_t)N * (t < T ? t : 0);
+        const double was = (r == 0 && t < T) ? v.prev_node[at] : 0.0;          // (on its way while the rows are read)
+        const int g0 = v.node_gitem_beg[n], ngi = v.node_gitem_beg[n + 1] - g0, s0 = v.node_sitem_beg[n], nsi = v.node_sitem_beg[n + 1] - s0;
+        redn[tid] = t < T ? rows_sum(v, g0, ngi, s0, nsi, 0, ngi + 2 * nsi, r, t) : 0.0;
         __syncthreads();
         if (r == 0 && t < T) {
             double sum = 0.0;
             for (int q = 0; q < 8; ++q) sum += redn[q * 32 + tt];
-            v.node_dsum[n + (size_t)N * t] = sum;
+            v.node_dsum[at] = sum - was;
+            v.prev_node[at] = sum;
+            if (v.slackInDual) v.cons[at] = sum;        // no k_reduce launch behind this one: the node's sum leaves from here
         }
-        if (v.slackInDual) {
-            // no k_reduce launch behind this one: the node's sum and the cost leave from here, with k_reduce's arithmetic
-            // (one slice per node) — the rows are in this CU's cache from the loop above
-            const int ngi = g1 - g0, nsi = s1 - s0;
-            const double acc = t < T ? rows_sum(v, g0, ngi, s0, nsi, 0, ngi + 2 * nsi, r, t) : 0.0;
-            __syncthreads();
-            redn[tid] = acc;
-            __syncthreads();
-            if (r == 0 && t < T) {
-                double sum = 0.0;
-                for (int q = 0; q < 8; ++q) sum += redn[q * 32 + tt];
-                v.cons[n + (size_t)N * t] = sum;
-            }
-            if (blockIdx.x == 0) {
-                __syncthreads();
-                const int ngr = v.genRows > 0 ? v.genRows : v.nGenItems;
-                const double c = cost_rows_sum(v, 0, ngr + v.nStoItems, ngr, redn);
-                if (tid == 0) v.cons[(size_t)N * T + 2 * (size_t)L * T] = c;
-            }
+        if (v.slackInDual && blockIdx.x == 0) {          // ... and the cost
+            const int ngr = v.genRows > 0 ? v.genRows : v.nGenItems;
+            const double c = cost_rows_sum(v, 0, ngr + v.nStoItems, ngr, redn);
+            if (tid == 0) v.cons[(size_t)N * T + 2 * (size_t)L * T] = c;
         }
     }
     {   // usually no (line, timestep) of this chunk has a switch point within anybody's reach: k_reduce takes the closed forms
@@ -649,21 +612,6 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
     }
 }
 
-
-// set_state support: the items' injection sums of the state handed in (what the next iteration's node changes refer to)
-__global__ __launch_bounds__(256) void k_derive_items(DevView v)
-{
-    const int T = v.T, nG = v.nGenItems;
-    const bool gen = (int)blockIdx.x < nG;
-    const Item it = gen ? v.gen_items[blockIdx.x] : v.sto_items[blockIdx.x - nG];
-    for (int t = threadIdx.x; t < T; t += 256) {
-        double sum = 0.0;
-        for (int a = it.a0; a < it.a1; ++a)
-            sum += gen ? v.P[(size_t)a * T + t] : v.D[(size_t)a * T + t] - v.C[(size_t)a * T + t];
-        if (gen) v.prev_ginj[(size_t)blockIdx.x * T + t] = sum;
-        else v.prev_sinj[(size_t)(blockIdx.x - nG) * T + t] = sum;
-    }
-}
 
 void launch_reduce(const DevView &v, hipStream_t s)
 {
@@ -1170,7 +1118,7 @@ __global__ __launch_bounds__(256) void k_price_t(DevView v)
 // line state is on its way while the flows are formed, mu - rho and the G / S terms of the linear pieces go from the
 // dual half to the price half through LDS, and the residual maxima meet in a ticket: the block that finishes last runs
 // the stop test (one atomic round trip per block instead of a launch). Every sum has a fixed order.
-template <bool UPDATE>
+template <bool UPDATE, bool SID = false>
 __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
 {
     const int halt = UPDATE ? v.st->halt : 0;           // (looked at once the first loads are on their way; nothing stored before)
@@ -1186,27 +1134,23 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
     const double g = v.gamma, w2 = 2.0 * v.w_flow, inv = 1.0 / (w2 + g);
 
     // ---- dual half: thread (node part pl, line l) --------------------------------------------------------------
-    // sid: the slack sums of this timestep's lines are formed HERE, from the PTDF rows the flows need anyway and the nodes'
+    // SID: the slack sums of this timestep's lines are formed HERE, from the PTDF rows the flows need anyway and the nodes'
     // injection changes (k_slack) — with k_reduce's arithmetic, part by part — instead of by a launch in between
-    const bool sid = UPDATE && v.slackInDual;
+    constexpr bool sid = UPDATE && SID;
     double *sdL = sh + N + 3 * L + (size_t)v.tablesInDual * (4 * v.M2 + 1), *winL = sdL + N, *naL = winL + N;
     const int pl = tid >> 8, l = tid & 255;
     const bool lt = pl == 0 && l < L;
     const size_t i = (size_t)(l < L ? l : 0) + (size_t)L * t;
     const int Nc = (((N + 3) / 4) + 7) & ~7, nbeg = pl * Nc, nend = min(N, nbeg + Nc);
-    double f_old = 0.0, aU_old = 0.0, aK_old = 0.0, mo = 0.0, ro = 0.0, F = 0.0, sU = 0.0, sK = 0.0, reach = 0.0, cntp = 0.0;
+    const bool mine = sid && l < L && nbeg < nend;           // this thread forms a part of the slack sums of line l
+    double f_old = 0.0, aU_old = 0.0, aK_old = 0.0, F = 0.0, cntp = 0.0;
     int wf = 0;
-    if (lt || (sid && l < L)) {                  // (in flight while the flows are formed)
+    if (lt || mine) {                            // (in flight while the flows are formed)
         f_old = v.flow[i]; aU_old = v.avgU[i]; aK_old = v.avgK[i]; F = v.fmax[l];
     }
-    if (lt) {
-        mo = v.mu[i]; ro = v.rho[i]; reach = v.line_reach[l];
-        if (!sid) { sU = cU[i]; sK = cK[i]; }
-    }
-    if (sid && l < L) {
+    if (mine) {
         wf = v.walk_flag[i];
-        if (nbeg < nend)                         // agents at the part's nodes
-            cntp = (double)((v.node_gen_beg[nend] - v.node_gen_beg[nbeg]) + (v.node_sto_beg[nend] - v.node_sto_beg[nbeg]));
+        cntp = (double)((v.node_gen_beg[nend] - v.node_gen_beg[nbeg]) + (v.node_sto_beg[nend] - v.node_sto_beg[nbeg]));   // agents at the part's nodes
     }
     const double lam_old = v.lam[t], s_old = v.s[t];
     double x = 0.0;
@@ -1220,21 +1164,37 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         for (int d = 32; d > 0; d >>= 1) ps += __shfl_xor(ps, d);
         if (lane == 0 && tid < 256) wsum[tid >> 6] = ps;
     }
-    const int anyWalk = __syncthreads_or(wf);
+    const int anyWalk = sid ? __syncthreads_or(wf) : (__syncthreads(), 0);
     if (halt) return;                                    // (uniform)
-    if (anyWalk) {                                       // (rare, uniform) a line of t has its switch point inside a node's window
+    if (sid && anyWalk) {
+        // (rare, uniform) a line of t has its switch point inside some node's window: the parts of those lines' sums, node
+        // by node, before anything else is held in registers
         if (tid < N) {
             winL[tid] = v.node_win[tid];
             naL[tid] = (double)((v.node_gen_beg[tid + 1] - v.node_gen_beg[tid]) + (v.node_sto_beg[tid + 1] - v.node_sto_beg[tid]));
         }
         __syncthreads();
+        if (mine && wf) {
+            double pu, pk;
+            slack_sum_cases_both(v.self, l, t, nbeg, nend, sdL, winL, naL, f_old, F, aU_old, aK_old, &pu, &pk);
+            red[1][tid] = pu; red[2][tid] = pk;
+        }
     }
     if (tid < N) v.inj[tid + (size_t)N * t] = x;
     const double sum = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
-    const double ln = UPDATE ? lam_old + g * sum : lam_old;                     // update_duals.jl:8-13
+    // (the imbalance and the new lambda are needed again at the kernel's end: parked in LDS, not in registers the dot
+    // products need — the compiler spilled them to scratch)
+    __shared__ double parked[2];
     if (tid == 0) {
-        if (UPDATE) { v.s_used[t] = s_old; v.lam_used[t] = lam_old; v.lam[t] = ln; }
+        const double ln0 = UPDATE ? lam_old + g * sum : lam_old;                 // update_duals.jl:8-13
+        if (UPDATE) { v.s_used[t] = s_old; v.lam_used[t] = lam_old; v.lam[t] = ln0; }
         v.s[t] = sum;
+        parked[0] = sum; parked[1] = ln0;
+    }
+    double mo = 0.0, ro = 0.0, sU = 0.0, sK = 0.0, reach = 0.0;
+    if (lt) {
+        mo = v.mu[i]; ro = v.rho[i]; reach = v.line_reach[l];
+        if (!sid) { sU = cU[i]; sK = cK[i]; }
     }
     double f = 0.0, ds = 0.0;
     if (l < L)
@@ -1251,16 +1211,12 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
             }
         }
     red[0][tid] = f;
-    if (sid) {
+    if (sid && !wf) {
         double pu = 0.0, pk = 0.0;
-        if (l < L && nbeg < nend) {
-            if (!wf) {
-                const SlackCase c0 = slack_case(g, w2, inv, 0.0, f_old, F, aU_old, aK_old, 0.0);
-                if (c0.aU > 0.0) pu = slack_sum_plain(0, cntp, c0.aU, w2 * inv, ds);
-                if (c0.aK > 0.0) pk = slack_sum_plain(1, cntp, c0.aK, w2 * inv, ds);
-            } else {
-                slack_sum_cases_both(v.self, l, t, nbeg, nend, sdL, winL, naL, f_old, F, aU_old, aK_old, &pu, &pk);
-            }
+        if (mine) {
+            const SlackCase c0 = slack_case(g, w2, inv, 0.0, f_old, F, aU_old, aK_old, 0.0);
+            if (c0.aU > 0.0) pu = slack_sum_plain(0, cntp, c0.aU, w2 * inv, ds);
+            if (c0.aK > 0.0) pk = slack_sum_plain(1, cntp, c0.aK, w2 * inv, ds);
         }
         red[1][tid] = pu; red[2][tid] = pk;
     }
@@ -1309,7 +1265,7 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
     // residual maxima of this timestep: issued here, they return while the price half runs (see the ticket at the end)
     unsigned long long r0_ = 0, r1_ = 0, r2_ = 0;
     if (UPDATE && tid == 0) {
-        const double rl = fabs(ln - lam_old);
+        const double rl = fabs(parked[1] - lam_old);
         const double bm = fmax(fmax(wmx[0][0], wmx[0][1]), fmax(wmx[0][2], wmx[0][3]));
         const double br = fmax(fmax(wmx[1][0], wmx[1][1]), fmax(wmx[1][2], wmx[1][3]));
         if (rl > 0.0) r0_ = atomicMax(&v.st->resbits[0], (unsigned long long)__double_as_longlong(rl));
@@ -1340,11 +1296,11 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
     if (pp == 0 && n < N) {
         for (int k = 1; k < P; ++k) { pr += red[0][k * NP + n]; psx += red[1][k * NP + n]; sl += red[2][k * NP + n]; }
         const size_t at = n + (size_t)N * t;
-        pr += ln;
+        pr += parked[1];
         v.price[at] = pr;
         if (lin) {
             v.tb_m[at] = 0;
-            v.tb_psi0[at] = (pr + g * sum) + psx;
+            v.tb_psi0[at] = (pr + g * parked[0]) + psx;
             v.tb_slope[at * (v.M2 + 1)] = g + sl;
         }
     }
@@ -1592,6 +1548,7 @@ static size_t t1024_lds(const DevView &v)
     static bool raised = false;
     if (bytes > 48 * 1024 && !raised) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_dual_price_t1024<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_dual_price_t1024<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_dual_price_t1024<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         raised = true;
     }
@@ -1608,7 +1565,8 @@ void launch_dual(const DevView &v, hipStream_t s, const XchgView *xd)
         return;
     }
     if (v.L > 0 && v.L <= 256 && v.N <= 256 && !v.splitDual) {
-        hipLaunchKernelGGL(k_dual_price_t1024<true>, dim3(v.T), dim3(1024), t1024_lds(v), s, v);
+        if (v.slackInDual) hipLaunchKernelGGL((k_dual_price_t1024<true, true>), dim3(v.T), dim3(1024), t1024_lds(v), s, v);
+        else hipLaunchKernelGGL(k_dual_price_t1024<true>, dim3(v.T), dim3(1024), t1024_lds(v), s, v);
         return;
     }
     if ((size_t)std::max(v.N, 3 * v.L) * sizeof(double) <= 48 * 1024) {
@@ -1634,6 +1592,7 @@ __global__ __launch_bounds__(256) void k_derive_cons(DevView v)
     for (int g = v.node_gen_beg[n]; g < v.node_gen_beg[n + 1]; ++g) sum += v.P[(size_t)g * T + t];
     for (int s = v.node_sto_beg[n]; s < v.node_sto_beg[n + 1]; ++s) sum += v.D[(size_t)s * T + t] - v.C[(size_t)s * T + t];
     v.cons[i] = sum;
+    if (v.L > 0) v.prev_node[i] = sum;        // what the next iteration's node changes refer to
 }
 
 __global__ __launch_bounds__(256) void k_derive_level(DevView v)
@@ -1688,8 +1647,6 @@ void launch_derive(const DevView &v, hipStream_t s, bool from_primal)
     if (from_primal) {        // serial over a node's agents: fine for tests / resume, not a hot path
         hipLaunchKernelGGL(k_derive_cons, dim3((unsigned)((NT + 255) / 256)), dim3(256), 0, s, v);
         if (v.S > 0) hipLaunchKernelGGL(k_derive_level, dim3((unsigned)((v.S + 255) / 256)), dim3(256), 0, s, v);
-        if (v.L > 0 && v.nGenItems + v.nStoItems > 0)
-            hipLaunchKernelGGL(k_derive_items, dim3(v.nGenItems + v.nStoItems), dim3(256), 0, s, v);
     }
     if (n1 <= kSmallConsensus) {
         hipLaunchKernelGGL((k_dual_price_small<false, false>), dim3(1), dim3(256), 0, s, v, XchgView{});
