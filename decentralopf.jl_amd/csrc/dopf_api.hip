@@ -184,6 +184,8 @@ int read_status(dopf_ctx *c)
     HIPCHK(c, hipMemcpyAsync(dst, c->v.st, sizeof(Status), hipMemcpyDeviceToHost, c->main));
     HIPCHK(c, hipStreamSynchronize(c->main));
     if (c->host_pin) c->host_st = *c->host_pin;
+    if (c->host_st.res_set == 0 || c->host_st.res_set == 1)       // (k_dual_price_t1024 leaves the maxima as bit patterns, see Status)
+        for (int k = 0; k < 3; ++k) memcpy(&c->host_st.res[k], &c->host_st.resbits2[c->host_st.res_set][k], sizeof(double));
     return DOPF_OK;
 }
 
@@ -529,6 +531,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     TRY(dev_alloc(c, &v.st, 1));
     Status st0{};
     st0.iteration = 1;                                      // admm.jl:29
+    st0.res_set = -1;
     HIPTRY(hipMemcpyAsync(v.st, &st0, sizeof st0, hipMemcpyHostToDevice, c->main));
     // "no result yet" state: zeros everywhere, injection = -demand (helpers/results.jl:14-73)
     launch_derive(v, c->main, false);     // all-zero primal state: the consensus buffer is already zero
@@ -918,6 +921,7 @@ int dopf_set_state(dopf_ctx *c, const double *P, const double *D, const double *
     st.converged = 0;
     st.halt = (v.max_iters > 0 && iteration > v.max_iters);
     st.resbits[0] = st.resbits[1] = st.resbits[2] = 0;
+    memset(st.resbits2, 0, sizeof st.resbits2);
     HIPCHK(c, hipMemcpy(v.st, &st, sizeof st, hipMemcpyHostToDevice));
     launch_derive(v, c->main, true);
     HIPCHK(c, hipGetLastError());

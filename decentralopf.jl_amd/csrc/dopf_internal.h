@@ -38,6 +38,9 @@ struct Status {
     unsigned long long dbg_cyc[6];                              // DOPF_STATS: wave cycles per section of the storage body
     unsigned long long dbg_reason[4];                           // DOPF_STATS: no prices / Newton / level / sign
     unsigned long long resbits[3];   // running max of |dual change| as bit patterns (>= 0 doubles)
+    unsigned long long resbits2[2][3];   // k_dual_price_t1024: the same, one set per iteration parity (the stop test does not read them:
+                                         // its ticket word carries "some residual >= eps"); the host decodes the reported set
+    int res_set;                    // -1: res[] holds the residuals of the last checked iteration; 0/1: resbits2[res_set] does
     double res[3];          // lambda / mu / rho residual inf-norms of the last checked iteration
     double total_cost;
     int xchg_timeout;       // peer exchange: a peer's part of the consensus sum did not arrive in time (sticky)
@@ -121,7 +124,8 @@ struct DevView {
     int *tab_skip;                                  // [t] the price kernel has written the (empty) tables of timestep t
     int *walk_flag, *walk_any;                      // [l + L*t], [t]: the slack sums of (l,t) need the per-node cases (set by the dual step)
     double *part2, *part2_cost;                     // [(n*RB + rb)*T + t], [rb]
-    int *dual_ticket;                               // [1] blocks of the one-launch dual/price kernel that have finished
+    unsigned long long *dual_ticket;                // [1] one-launch dual/price kernel: blocks whose residuals are in (low word) and how many
+                                                    // of them saw a residual >= eps (high word)
     // One-launch iterations (one node, no lines, single-GPU chain; kernels_agents.hip "the tail of the iteration inside the
     // x-update launch"): every block of the x-update adds its per-timestep injection sums and its cost into integer
     // accumulators (fixed point + arrival count in one 64-bit atomic add), and one extra block of the launch waits for the
@@ -161,6 +165,7 @@ __device__ __forceinline__ void status_update(const DevView &v, const StatusPre 
     int conv = s.converged, it = s.iteration;
     if (it != 1) {                                                        // convergence.jl:3
         st->res[0] = r0; st->res[1] = r1; st->res[2] = r2;
+        st->res_set = -1;
         conv = (r0 < v.eps) && (r1 < v.eps) && (r2 < v.eps);
         st->converged = conv;
     }

@@ -1122,6 +1122,7 @@ template <bool UPDATE, bool SID = false>
 __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
 {
     const int halt = UPDATE ? v.st->halt : 0;           // (looked at once the first loads are on their way; nothing stored before)
+    const StatusPre spre = UPDATE ? status_load(v) : StatusPre{0, 0, 0};       // (what the stop test starts from: loaded now, used at the end)
     extern __shared__ double sh[];               // q[N] injections | d[L] mu - rho | G[L] | S[L]
     __shared__ double red[3][1024];
     __shared__ double wsum[4], wmx[2][4];
@@ -1262,35 +1263,60 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
     const int anyNeed = wany[0] | wany[1] | wany[2] | wany[3];
     const int nz = wnz[0] | wnz[1] | wnz[2] | wnz[3];
     const bool lin = !anyNeed;
-    // residual maxima of this timestep: issued here, they return while the price half runs (see the ticket at the end)
-    unsigned long long r0_ = 0, r1_ = 0, r2_ = 0;
-    if (UPDATE && tid == 0) {
-        const double rl = fabs(parked[1] - lam_old);
-        const double bm = fmax(fmax(wmx[0][0], wmx[0][1]), fmax(wmx[0][2], wmx[0][3]));
-        const double br = fmax(fmax(wmx[1][0], wmx[1][1]), fmax(wmx[1][2], wmx[1][3]));
-        if (rl > 0.0) r0_ = atomicMax(&v.st->resbits[0], (unsigned long long)__double_as_longlong(rl));
-        if (bm > 0.0) r1_ = atomicMax(&v.st->resbits[1], (unsigned long long)__double_as_longlong(bm));
-        if (br > 0.0) r2_ = atomicMax(&v.st->resbits[2], (unsigned long long)__double_as_longlong(br));
-    }
-
+    // Stop test, part 1 (thread 0). The residual maxima of this timestep go into this iteration's set of maxima words as
+    // device-scope atomics nobody waits for (the host decodes them), and ONE 64-bit add draws the ticket: low word = blocks
+    // that are this far, high word = how many of them saw a residual >= eps. The block that draws the last ticket knows
+    // from the returned word alone whether the iteration converged — no second round trip for the maxima, and the one
+    // round trip there is runs under the end of the price half (see below).
     // ---- price half: thread (line part pp, node n) -------------------------------------------------------------
     const int NP = N <= 128 ? 128 : 256, P = 1024 / NP;
     const int pp = tid / NP, n = tid - pp * NP;
     const int Lc = (((L + P - 1) / P) + 7) & ~7, lbeg = pp * Lc, lend = min(L, lbeg + Lc);
     double pr = 0.0, psx = 0.0, sl = 0.0;
-    if (n < N && (nz || lin))
-        for (int l0 = lbeg; l0 < lend; l0 += kFlight) {                        // ptdfT[n + N l]: coalesced over the nodes
-            double h[kFlight];
+    const bool priced = n < N && (nz || lin);
+    auto batch_use = [&](const double (&h)[kFlight], int l0) {
 #pragma unroll
-            for (int u = 0; u < kFlight; ++u) h[u] = l0 + u < lend ? v.ptdfT[n + (size_t)N * (l0 + u)] : 0.0;
-#pragma unroll
-            for (int u = 0; u < kFlight; ++u) {
-                if (l0 + u < lend) {
-                    pr += h[u] * dd[l0 + u];
-                    if (lin) { psx += h[u] * Gl[l0 + u]; sl += h[u] * h[u] * Sl[l0 + u]; }
-                }
+        for (int u = 0; u < kFlight; ++u) {
+            if (l0 + u < lend) {
+                pr += h[u] * dd[l0 + u];
+                if (lin) { psx += h[u] * Gl[l0 + u]; sl += h[u] * h[u] * Sl[l0 + u]; }
             }
         }
+    };
+    // batches of kFlight rows (ptdfT[n + N l]: coalesced over the nodes): all but the last ...
+    int l0 = lbeg;
+    if (priced)
+        for (; l0 + kFlight < lend; l0 += kFlight) {
+            double h[kFlight];
+#pragma unroll
+            for (int u = 0; u < kFlight; ++u) h[u] = v.ptdfT[n + (size_t)N * (l0 + u)];
+            batch_use(h, l0);
+        }
+    if (priced) {                                   // ... and the last one
+        double h[kFlight];
+#pragma unroll
+        for (int u = 0; u < kFlight; ++u) h[u] = l0 + u < lend ? v.ptdfT[n + (size_t)N * (l0 + u)] : 0.0;
+        batch_use(h, l0);
+    }
+    // The ticket is drawn HERE, behind the last use of a load: a wave's vector memory operations retire through one counter,
+    // and with an atomic among them the compiler can only wait for all of them (vmcnt(0)) — drawn in front of the price
+    // half, it held that wave's PTDF rows back for its 2.5 us. What is left of the round trip runs under the barrier, the
+    // sums and the stores below. (The address goes through a register the compiler knows nothing about: for an address it
+    // can prove uniform it rewrites the add into a wave-wide one whose result it reads back at once.)
+    unsigned long long tk_ = 0, viol_ = 0;
+    if (UPDATE && tid == 0) {
+        const double rl = fabs(parked[1] - lam_old);
+        const double bm = fmax(fmax(wmx[0][0], wmx[0][1]), fmax(wmx[0][2], wmx[0][3]));
+        const double br = fmax(fmax(wmx[1][0], wmx[1][1]), fmax(wmx[1][2], wmx[1][3]));
+        unsigned long long *rb = v.st->resbits2[spre.iters_total & 1];
+        if (rl > 0.0) (void)__hip_atomic_fetch_max(&rb[0], (unsigned long long)__double_as_longlong(rl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bm > 0.0) (void)__hip_atomic_fetch_max(&rb[1], (unsigned long long)__double_as_longlong(bm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (br > 0.0) (void)__hip_atomic_fetch_max(&rb[2], (unsigned long long)__double_as_longlong(br), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        viol_ = (rl < v.eps && bm < v.eps && br < v.eps) ? 0ull : 1ull;               // convergence.jl:15-23
+        int zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+        tk_ = atomicAdd(v.dual_ticket + zero, 1ull | (viol_ << 32));
+    }
     red[0][tid] = pr; red[1][tid] = psx; red[2][tid] = sl;
     __syncthreads();
     if (pp == 0 && n < N) {
@@ -1316,24 +1342,24 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         if (wv < TW)
             for (int nn = wv; nn < N; nn += TW) build_table(v, nn, t, tsh);
     }
-    if (UPDATE) {
-        // residual maxima of this timestep, then the ticket: whoever is last has every block's maxima behind it
-        if (tid == 0) {
-            // Nothing but the three maxima travels from the other blocks to the last one, and they travel in device-scope
-            // atomics (performed at the memory side, past the per-XCD L2s). So no release fence — that would write this
-            // XCD's whole L2 back — only: the maxima have RETURNED before the ticket is drawn.
-            if (t == 0) v.st->total_cost = v.cons[NT + 2 * LT];
-            asm volatile("s_waitcnt vmcnt(0)" ::"v"(r0_), "v"(r1_), "v"(r2_) : "memory");
-            const int last = atomicAdd(v.dual_ticket, 1) == T - 1;
-            if (last) {
-                Status *st = v.st;
-                const double r0 = __longlong_as_double((long long)__hip_atomic_load(&st->resbits[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                const double r1 = __longlong_as_double((long long)__hip_atomic_load(&st->resbits[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                const double r2 = __longlong_as_double((long long)__hip_atomic_load(&st->resbits[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                st->resbits[0] = st->resbits[1] = st->resbits[2] = 0ull;
-                *v.dual_ticket = 0;
-                status_update(v, r0, r1, r2);
+    if (UPDATE && tid == 0) {
+        // Stop test, part 2: whoever drew the last ticket has every block's verdict in the word it got back
+        if (t == 0) v.st->total_cost = v.cons[NT + 2 * LT];
+        if ((unsigned)(tk_ & 0xffffffffull) == (unsigned)(T - 1)) {
+            Status *st = v.st;
+            const int par = spre.iters_total & 1;
+            st->resbits2[1 - par][0] = st->resbits2[1 - par][1] = st->resbits2[1 - par][2] = 0ull;      // the next iteration's set
+            *v.dual_ticket = 0ull;
+            int conv = spre.converged, it = spre.iteration;
+            if (it != 1) {                                                        // convergence.jl:3
+                conv = (tk_ >> 32) + viol_ == 0ull;
+                st->converged = conv;
+                st->res_set = par;
             }
+            st->iters_total = spre.iters_total + 1;
+            if (!conv) it += 1;                                                   // convergence.jl:25-30
+            st->iteration = it;
+            st->halt = conv || (v.max_iters > 0 && it > v.max_iters);
         }
     }
 }

@@ -13,7 +13,7 @@ api = _capi.CApi(LIB, "dopf_") if LIB else _capi.hip_api()
 for wl in sys.argv[1:] or ["config2"]:
     pp = bench.make_problem(synth, wl)
     A = pp.G + pp.S
-    for flags in (0, _capi.F_NO_TAIL_FUSE):
+    for flags in ([int(x) for x in os.environ["FLAGS"].split(",")] if os.environ.get("FLAGS") else (0, _capi.F_NO_TAIL_FUSE)):
         e = _capi.Engine(api, params=_capi.default_params(gamma=1.0 / A, w_flow=10.0 if pp.L == 0 else 0.3 / A, eps=0.0, flags=flags),
                          **pp.engine_kwargs())
         a = torch.randn(2048, 2048, device="cuda")
