@@ -1123,6 +1123,10 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
 {
     const int halt = UPDATE ? v.st->halt : 0;           // (looked at once the first loads are on their way; nothing stored before)
     const StatusPre spre = UPDATE ? status_load(v) : StatusPre{0, 0, 0};       // (what the stop test starts from: loaded now, used at the end)
+    const int tid0_ = threadIdx.x, t0_ = blockIdx.x;
+#ifdef DOPF_DUAL_STAMPS
+    if (UPDATE && tid0_ == 0 && t0_ == v.T / 2) v.st->dbg_reason[0] = wall_clock64();
+#endif
     extern __shared__ double sh[];               // q[N] injections | d[L] mu - rho | G[L] | S[L]
     __shared__ double red[3][1024];
     __shared__ double wsum[4], wmx[2][4];
@@ -1166,6 +1170,10 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         if (lane == 0 && tid < 256) wsum[tid >> 6] = ps;
     }
     const int anyWalk = sid ? __syncthreads_or(wf) : (__syncthreads(), 0);
+
+#ifdef DOPF_DUAL_STAMPS
+    if (UPDATE && tid == 0 && t == T / 2) v.st->dbg_reason[1] = wall_clock64();
+#endif
     if (halt) return;                                    // (uniform)
     if (sid && anyWalk) {
         // (rare, uniform) a line of t has its switch point inside some node's window: the parts of those lines' sums, node
@@ -1211,6 +1219,10 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
                     if (n0 + u < nend) ds = fma(h[u], sdL[n0 + u], ds);
             }
         }
+
+#ifdef DOPF_DUAL_STAMPS
+    if (UPDATE && tid == 0 && t == T / 2) v.st->dbg_reason[2] = wall_clock64();
+#endif
     red[0][tid] = f;
     if (sid && !wf) {
         double pu = 0.0, pk = 0.0;
@@ -1222,6 +1234,10 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         red[1][tid] = pu; red[2][tid] = pk;
     }
     __syncthreads();
+
+#ifdef DOPF_DUAL_STAMPS
+    if (UPDATE && tid == 0 && t == T / 2) v.st->dbg_reason[3] = wall_clock64();
+#endif
     double rm = 0.0, rr = 0.0;
     int flag = 0, nzl = 0;
     if (lt) {
@@ -1268,6 +1284,10 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
     // that are this far, high word = how many of them saw a residual >= eps. The block that draws the last ticket knows
     // from the returned word alone whether the iteration converged — no second round trip for the maxima, and the one
     // round trip there is runs under the end of the price half (see below).
+
+#ifdef DOPF_DUAL_STAMPS
+    if (UPDATE && tid == 0 && t == T / 2) v.st->dbg_cyc[0] = wall_clock64();
+#endif
     // ---- price half: thread (line part pp, node n) -------------------------------------------------------------
     const int NP = N <= 128 ? 128 : 256, P = 1024 / NP;
     const int pp = tid / NP, n = tid - pp * NP;
@@ -1298,6 +1318,10 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         for (int u = 0; u < kFlight; ++u) h[u] = l0 + u < lend ? v.ptdfT[n + (size_t)N * (l0 + u)] : 0.0;
         batch_use(h, l0);
     }
+
+#ifdef DOPF_DUAL_STAMPS
+    if (UPDATE && tid == 0 && t == T / 2) v.st->dbg_cyc[1] = wall_clock64();
+#endif
     // The ticket is drawn HERE, behind the last use of a load: a wave's vector memory operations retire through one counter,
     // and with an atomic among them the compiler can only wait for all of them (vmcnt(0)) — drawn in front of the price
     // half, it held that wave's PTDF rows back for its 2.5 us. What is left of the round trip runs under the barrier, the
@@ -1319,6 +1343,10 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
     }
     red[0][tid] = pr; red[1][tid] = psx; red[2][tid] = sl;
     __syncthreads();
+
+#ifdef DOPF_DUAL_STAMPS
+    if (UPDATE && tid == 0 && t == T / 2) v.st->dbg_cyc[2] = wall_clock64();
+#endif
     if (pp == 0 && n < N) {
         for (int k = 1; k < P; ++k) { pr += red[0][k * NP + n]; psx += red[1][k * NP + n]; sl += red[2][k * NP + n]; }
         const size_t at = n + (size_t)N * t;
@@ -1342,10 +1370,18 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         if (wv < TW)
             for (int nn = wv; nn < N; nn += TW) build_table(v, nn, t, tsh);
     }
+
+#ifdef DOPF_DUAL_STAMPS
+    if (UPDATE && tid == 0 && t == T / 2) v.st->dbg_cyc[3] = wall_clock64();
+#endif
     if (UPDATE && tid == 0) {
         // Stop test, part 2: whoever drew the last ticket has every block's verdict in the word it got back
         if (t == 0) v.st->total_cost = v.cons[NT + 2 * LT];
-        if ((unsigned)(tk_ & 0xffffffffull) == (unsigned)(T - 1)) {
+        const bool last_ = (unsigned)(tk_ & 0xffffffffull) == (unsigned)(T - 1);
+#ifdef DOPF_DUAL_STAMPS
+        if (t == T / 2) v.st->dbg_cyc[4] = wall_clock64();        // (the ticket has returned)
+#endif
+        if (last_) {
             Status *st = v.st;
             const int par = spre.iters_total & 1;
             st->resbits2[1 - par][0] = st->resbits2[1 - par][1] = st->resbits2[1 - par][2] = 0ull;      // the next iteration's set
