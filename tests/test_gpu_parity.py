@@ -75,6 +75,8 @@ SYNTH = [
     ("storages-only", dict(n_gen=0, n_sto=12, T=24, seed=14), dict(gamma=0.05), 1, 10, 1e-9),
     ("net-100x300-more-lines-than-one-block (k_dual_t + k_price_t)", dict(n_gen=150, n_sto=20, T=24, N=100, L=300, seed=23, fmax_factor=0.7, fmax_min=20), dict(gamma=0.01), 1, 4, 1e-7),
     ("net-118x186-config3-shape", dict(n_gen=900, n_sto=90, T=12, N=118, L=186, seed=19, fmax_factor=0.7, fmax_min=20), dict(gamma=0.002), 1, 4, 1e-7),
+    ("net-30x45-T96-three-launch-chain (k_net_agents, k_slack, k_dual_price_t1024 with the slack sums)",
+     dict(n_gen=120, n_sto=24, T=96, N=30, L=45, seed=41, fmax_factor=0.7, fmax_min=10), dict(gamma=0.01), 1, 5, 1e-7),
 ]
 
 
@@ -107,6 +109,28 @@ def test_hip_free_running_trajectory(hip_api, oracle_api):
     h.iterate(200)
     o.iterate(200)
     assert max_diff(state_of(h), state_of(o), keys=["P", "D", "C", "E", "lam", "inj"])[0] < 1e-8
+
+
+def test_hip_free_running_network_on_the_three_launch_chain(hip_api, oracle_api):
+    """30 nodes / 45 lines x 96 timesteps (consensus state beyond the one-block dual kernel: generators and storages in one
+    launch, node sums and their changes from k_slack, slack sums formed by the dual/price kernel), no state resets: 30
+    iterations side by side with the oracle's exact mode — through the iterations in which lines are flagged and agents are
+    walked one by one, and the ones after."""
+    pp = synth.synthetic_case(120, 24, 96, N=30, L=45, seed=43, fmax_factor=0.8, fmax_min=10)
+    A = pp.G + pp.S
+    kw = dict(eps=0.0, gamma=1.0 / A, w_flow=0.3 / A)
+    h = make_engine(hip_api, pp, **kw)
+    o = make_engine(oracle_api, pp, mode=1, **kw)
+    assert h.iterate_timed(1)["agents_fused"] == 1
+    o.iterate(1)
+    for n in (1, 3, 10, 15):
+        h.iterate(n)
+        o.iterate(n)
+        sh, so = state_of(h), state_of(o)
+        scale = max(1.0, float(np.abs(so["lam"]).max()))
+        worst, where = max_diff(sh, so, keys=[x for x in sh if x != "cost"])
+        assert worst <= 1e-7 * scale, (n, where, worst)
+    assert h.solver_failures() == 0
 
 
 def test_hip_warm_start_is_exact_and_used(hip_api, oracle_api):
