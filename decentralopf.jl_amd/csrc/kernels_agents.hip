@@ -1913,11 +1913,15 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
             DOPF_TOC(2)
             DOPF_STAMP(4)
             if (!gdone && cert) {
+                // (the rows' addresses are formed again from the storage's index: held since the loads at the top they are six
+                // registers the solve in between spills for)
+                int s_ = s;
+                asm volatile("" : "+v"(s_));
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const int t = tbase + c;
                     if (t < T) {
-                        const size_t e = (size_t)s * T + t;
+                        const size_t e = (size_t)s_ * T + t;
                         v.D[e] = Dv[c];
                         v.C[e] = Cv[c];
                         // (nu + theta, see the loads; theta back from the step's offsets: B0 - A0 = w (c0 - d0) + 2 theta. Kept in
