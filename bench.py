@@ -55,6 +55,19 @@ SHARE = {"config3-share": 0.125}
 PEAK_GBPS = 8000.0        # HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
 
 
+def pmc_iteration_traffic(wl_):
+    """HBM bytes of ONE iteration (all kernels of the chain) from the committed PMC passes, or None"""
+    for tag in ("r03", "r02"):
+        f_ = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
+        if os.path.exists(f_):
+            recs = {k: r for k, r in json.load(open(f_)).get(wl_, {}).items()
+                    if k.startswith(("k_agents", "k_net_agents", "k_gen_update", "k_sto", "k_reduce", "k_dual_price_small<true", "k_dual_price_t1024<true",
+                                     "k_tables", "k_slack")) and r.get("FETCH_SIZE") is not None and r.get("WRITE_SIZE") is not None}
+            if recs:
+                return sum((2.0 * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024.0 for r in recs.values()), f"profiles/{tag}_pmc.json"
+    return None, None
+
+
 def make_problem(synth, wl, scale=1.0):
     idx = WORKLOADS[wl][0]
     if idx == 5:
@@ -539,7 +552,7 @@ def main():
             rows = bs // (pp.T // 2) if pair else 1
             row_skip = pair and not (args.flags & _capi.F_NO_ROW_SKIP) and max(rows, -(-pp.G // 2048)) >= 8 * rows    # as dopf_create decides
             if fused:       # ONE launch does every x-update: generators and storages
-                kname, alg_b = "k_agents", whole_b
+                kname, alg_b = ("k_agents" if pp.L == 0 else "k_net_agents"), whole_b
             else:
                 kname = ("k_gen_update_pair_skip" if row_skip else "k_gen_update_pair") if pair else "k_gen_update"
                 alg_b = gen_b + shared_b
@@ -547,8 +560,9 @@ def main():
             # of an empty pair's cost overlaps with a real kernel's own launch). The overhead used here is the one that makes
             # the kernels of an iteration ADD UP to the per-iteration time of the graph replay (no events in there): live,
             # no constant. rocprofv3's per-kernel durations agree with it (profiles/).
-            launched = ["gen_ms"] + ([] if fused else ["sto_ms"]) + (["tables_ms", "slack_ms"] if pp.L > 0 else []) + \
-                       ([] if tail else ["reduce_ms", "dual_ms"])
+            launched = ["gen_ms"] + ([] if fused else ["sto_ms"]) + (["slack_ms"] if pp.L > 0 else []) + \
+                       (["tables_ms"] if pp.L > 0 and timing["tables_ms"] > 1.5 * timing["empty_ms"] else []) + \
+                       ([] if tail else ([] if timing.get("slack_in_dual") else ["reduce_ms"]) + ["dual_ms"])
 
             def overhead(tm, per_iter_ms):
                 return min(tm["empty_ms"], max(0.0, (sum(tm[k] for k in launched) - per_iter_ms) / len(launched)))
@@ -601,8 +615,13 @@ def main():
                                                            "(all launches and the gaps between them)"}}
             if row_skip:
                 out["roofline"]["algorithmic_GBps"] = alg_b / (k_ms * 1e-3) / 1e9
+                trf_all, src_all = pmc_iteration_traffic(args.workload)
+                if trf_all is not None:      # (the model's bytes are not moved: what the memory system did, all kernels of the iteration)
+                    out["roofline"]["whole_iteration"].update({"hbm_traffic": trf_all, "hbm_traffic_source": src_all,
+                                                               "hbm_traffic_frac": trf_all / it_ms * 1e-6 / PEAK_GBPS})
             if fused:
-                out["roofline"]["what"] = ("all x-updates of an iteration in one launch: generator blocks stream P (HBM bound), storage "
+                out["roofline"]["what"] = ("all x-updates of an iteration in one launch: generator blocks " +
+                                           ("stream P (HBM bound)" if pp.L == 0 else "sweep P against the nodes' Psi tables") + ", storage "
                                            "blocks run the active-set SoC solve (fp64 VALU bound) on the same CUs" +
                                            ("; its last block adds up the blocks' sums and runs the dual step and the stop test" if tail else ""))
             out["kernels_ms"] = {k: v for k, v in timing.items() if k.endswith("_ms")}
@@ -678,17 +697,6 @@ def main():
         if not sharded and not args.no_also and args.scale == 1.0:
             # the other BASELINE configurations that fit one GPU, same engine, short runs (reported, not the metric)
             also = []
-            def pmc_iteration_traffic(wl_):
-                """HBM bytes of ONE iteration (all kernels of the chain) from the committed PMC passes, or None"""
-                for tag in ("r03", "r02"):
-                    f_ = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
-                    if os.path.exists(f_):
-                        recs = {k: r for k, r in json.load(open(f_)).get(wl_, {}).items()
-                                if k.startswith(("k_agents", "k_gen_update", "k_sto", "k_reduce", "k_dual_price_small<true", "k_dual_price_t1024<true",
-                                                 "k_tables", "k_slack")) and r.get("FETCH_SIZE") is not None and r.get("WRITE_SIZE") is not None}
-                        if recs:
-                            return sum((2.0 * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024.0 for r in recs.values()), f"profiles/{tag}_pmc.json"
-                return None, None
             for wl in ("config1", "config4", "config2", "config3-share", "config3", "config4x2"):
                 if wl == args.workload:
                     continue

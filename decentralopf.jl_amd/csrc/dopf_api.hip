@@ -699,6 +699,7 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
     out->iters = n_iters;
     out->agents_fused = v.fuseAgents || v.fuseNet;
     out->tail_fused = v.tail ? 1 : 0;
+    out->slack_in_dual = (!v.tail && v.slackInDual) ? 1 : 0;
     return DOPF_OK;
 }
 

@@ -214,6 +214,9 @@ typedef struct dopf_timing {
     int32_t agents_fused;   /* 1: generators and storages ran as one launch */
     int32_t tail_fused;     /* 1: consensus sums, dual step and stop test ran inside the x-update launch(es): reduce_ms and
                                dual_ms are empty event pairs */
+    int32_t slack_in_dual;  /* 1 (networks): node sums left from k_slack, slack sums were formed by the dual/price kernel:
+                               reduce_ms is an empty event pair */
+    int32_t reserved_;
 } dopf_timing;
 int dopf_iterate_timed(dopf_ctx *ctx, int32_t n_iters, dopf_timing *out);
 /* DOPF_F_TIME_CALLS: milliseconds between the first launch of the last dopf_iterate call and the end of its last one, on the
