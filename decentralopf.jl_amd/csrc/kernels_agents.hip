@@ -246,7 +246,7 @@ __device__ __forceinline__ void lin_coef(double w, double iw, double kap, double
 // One item of generators at a node of a network (tables of the node's Psi): a block of BS threads, thread (r, tt) of an R x TT
 // tiling, ceil(T / TT) column passes. k_gen_update<true> runs it with 512 threads, k_net_agents (generators and storages of a
 // network in ONE launch) with 256 and the same R — the same rows meet in the same order, the sums carry the same bits.
-template <int BS>
+template <int BS, int FL = 4>
 __device__ __forceinline__ void gen_lines_body(const DevView &v, const int item, const int TT, const int R)
 {
     __shared__ double red[BS];
@@ -269,15 +269,15 @@ __device__ __forceinline__ void gen_lines_body(const DevView &v, const int item,
             const double slope0 = slope[0];
             const double inv0 = rcp64(slope0 + w);             // (empty table: one piece for every agent of the node)
             const bool keepd = v.keepDeltas || v.walk_any[t];      // the change is needed agent by agent only for walked slack sums
-            for (int g0 = it.a0 + r; g0 < it.a1; g0 += 4 * R) {          // four agents' rows in flight per lane
-                double mc[4], pm[4], p0[4];
+            for (int g0 = it.a0 + r; g0 < it.a1; g0 += FL * R) {         // FL agents' rows in flight per lane (added in row order)
+                double mc[FL], pm[FL], p0[FL];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < FL; ++u) {
                     const int g = g0 + u * R < it.a1 ? g0 + u * R : g0;
                     mc[u] = v.gen_mc[g]; pm[u] = v.gen_pmax[g]; p0[u] = v.P[(size_t)g * T + t];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < FL; ++u) {
                     const int g = g0 + u * R;
                     if (g >= it.a1) break;
                     const size_t e = (size_t)g * T + t;
@@ -317,6 +317,102 @@ __device__ __forceinline__ void gen_lines_body(const DevView &v, const int item,
     for (int d = 32; d > 0; d >>= 1) cost += __shfl_xor(cost, d);
     if ((tid & 63) == 0) wcost[tid >> 6] = cost;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tid == 0) {
+        double c = 0.0;
+        for (int q = 0; q < BS / 64; ++q) c += wcost[q];
+        v.part_gcost[item] = c;
+    }
+}
+
+// The same item with the block's two column passes merged (needs 2 TT >= T: the 256-thread tiling of k_net_agents): thread
+// (r, tt) owns timesteps tt and tt + TT, both columns' tables and rows are on their way before anything is computed, and the
+// rows' costs are loaded once. A block of that launch is one of a few hundred that pass through the wave slots the storage
+// blocks leave free, each a chain of dependent round trips: two chains in parallel instead of one behind the other. Per
+// timestep the same rows meet in the same order as in gen_lines_body: the injection sums carry the same bits.
+template <int BS, int FL>
+__device__ __forceinline__ void gen_lines_body2(const DevView &v, const int item, const int TT, const int R)
+{
+    __shared__ double red[2][BS];
+    const Item it = v.gen_items[item];
+    const int T = v.T, N = v.N;
+    const int tid = threadIdx.x;
+    const int r = tid / TT, tt = tid - r * TT;
+    const double w = v.w_prox;
+    double cost = 0.0, acc[2] = {0.0, 0.0};
+    const bool on[2] = {r < R && tt < T, r < R && tt + TT < T};
+    if (on[0]) {
+        int m[2];
+        const double *beta[2], *psi[2], *slope[2];
+        double psi0[2], inv0[2];
+        bool keepd[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int t = on[c] ? tt + c * TT : tt;
+            const size_t at = (size_t)it.node + (size_t)N * t;
+            m[c] = v.tb_m[at];
+            beta[c] = v.tb_beta + at * v.M2; psi[c] = v.tb_psi + at * v.M2;
+            slope[c] = v.tb_slope + at * (v.M2 + 1);
+            psi0[c] = v.tb_psi0[at];
+            inv0[c] = slope[c][0];
+            keepd[c] = v.keepDeltas || v.walk_any[t];
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) inv0[c] = rcp64(inv0[c] + w);          // (empty table: one piece for every agent of the node)
+        for (int g0 = it.a0 + r; g0 < it.a1; g0 += FL * R) {              // FL agents' rows in flight per lane and column
+            double mc[FL], pm[FL], p0[2][FL];
+#pragma unroll
+            for (int u = 0; u < FL; ++u) {
+                const int g = g0 + u * R < it.a1 ? g0 + u * R : g0;
+                mc[u] = v.gen_mc[g]; pm[u] = v.gen_pmax[g];
+                p0[0][u] = v.P[(size_t)g * T + tt];
+                p0[1][u] = v.P[(size_t)g * T + (on[1] ? tt + TT : tt)];
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (!on[c]) continue;
+#pragma unroll
+                for (int u = 0; u < FL; ++u) {
+                    const int g = g0 + u * R;
+                    if (g >= it.a1) break;
+                    const size_t e = (size_t)g * T + tt + c * TT;
+                    double dl;
+                    if (m[c] == 0) {
+                        dl = -(mc[u] + psi0[c]) * inv0[c];
+                    } else {
+                        int lo = 0, hi = m[c];           // first kink with psi + w beta >= -mc
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (psi[c][mid] + w * beta[c][mid] >= -mc[u]) hi = mid; else lo = mid + 1;
+                        }
+                        const int a = lo < m[c] ? lo : m[c] - 1;
+                        dl = beta[c][a] - (mc[u] + psi[c][a] + w * beta[c][a]) * rcp64(slope[c][lo] + w);
+                    }
+                    const double pn = clampd(p0[c][u] + dl, 0.0, pm[u]);
+                    v.P[e] = pn;
+                    if (keepd[c]) v.dltG[e] = pn - p0[c][u];
+                    acc[c] += pn;
+                    cost += mc[u] * pn;
+                }
+            }
+        }
+    }
+    // fixed-order reduction over the R agent lanes that share a timestep (only LDS data crosses the barrier)
+    red[0][tid] = acc[0]; red[1][tid] = acc[1];
+    __shared__ double wcost[BS / 64];
+    for (int d = 32; d > 0; d >>= 1) cost += __shfl_xor(cost, d);
+    if ((tid & 63) == 0) wcost[tid >> 6] = cost;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (r == 0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int t = tt + c * TT;
+            if (tt < TT && t < T) {
+                double sum = 0.0;
+                for (int q = 0; q < R; ++q) sum += red[c][q * TT + tt];
+                v.part_ginj[(size_t)item * T + t] = sum;
+            }
+        }
+    }
     if (tid == 0) {
         double c = 0.0;
         for (int q = 0; q < BS / 64; ++q) c += wcost[q];
@@ -2041,6 +2137,9 @@ __global__ __launch_bounds__(256, DOPF_WARM_WAVES) void k_sto_warm(DevView v)
     }
 }
 
+#ifndef DOPF_NET_GEN_FLIGHT
+#define DOPF_NET_GEN_FLIGHT 4
+#endif
 // Networks, single-GPU chain: generators and storages in ONE launch — the storage items first (a block lives for the whole
 // launch: a chain of dependent round trips), the generator items behind them in 256-thread blocks that pass through the
 // wave slots the storages leave free. Alone, either launch is a few hundred short blocks bound by its own latency chain
@@ -2049,19 +2148,35 @@ template <int LPS, int NCH>
 __global__ __launch_bounds__(256, DOPF_WARM_WAVES) void k_net_agents(DevView v)
 {
     const int nS = v.nStoItems;
-    if ((int)blockIdx.x >= nS) {
+#ifdef DOPF_NET_GEN_FIRST            // (experiment: generator blocks in front)
+    const int nG_ = (int)gridDim.x - nS;
+    const bool isGen = (int)blockIdx.x < nG_;
+    const int gi = blockIdx.x, si = (int)blockIdx.x - nG_;
+#else
+    const bool isGen = (int)blockIdx.x >= nS;
+    const int gi = (int)blockIdx.x - nS, si = blockIdx.x;
+#endif
+#if defined(DOPF_STATS) || defined(DOPF_BLOCK_STAMPS)
+    if (threadIdx.x == 0 && blockIdx.x < 8192 * 4) g_timeline[32768 + 2 * blockIdx.x] = wall_clock64();
+#endif
+    if (isGen) {
         if (v.st->halt) return;
-        gen_lines_body<256>(v, blockIdx.x - nS, v.genTT256, v.genR);
-        return;
-    }
-    const int left = sto_warm_body<LPS, NCH, true>(v, blockIdx.x, v.st->halt);         // ends on a __syncthreads
-    if (left < 0) return;                                                               // halted
-    if (left == 0) {                         // (what the scan body writes when there is nothing for it)
-        for (int t = threadIdx.x; t < v.T; t += 256) v.part_sinj[(size_t)blockIdx.x * v.T + t] = 0.0;
-        if (threadIdx.x == 0) v.part_scost[blockIdx.x] = 0.0;
+        if (2 * v.genTT256 >= v.T) gen_lines_body2<256, DOPF_NET_GEN_FLIGHT>(v, gi, v.genTT256, v.genR);
+        else gen_lines_body<256, DOPF_NET_GEN_FLIGHT>(v, gi, v.genTT256, v.genR);
     } else {
-        sto_cold_lines_call<LPS, NCH>(v.self, blockIdx.x, left);
+        const int left = sto_warm_body<LPS, NCH, true>(v, si, v.st->halt);             // ends on a __syncthreads
+        if (left < 0) return;                                                           // halted
+        if (left == 0) {                     // (what the scan body writes when there is nothing for it)
+            for (int t = threadIdx.x; t < v.T; t += 256) v.part_sinj[(size_t)si * v.T + t] = 0.0;
+            if (threadIdx.x == 0) v.part_scost[si] = 0.0;
+        } else {
+            sto_cold_lines_call<LPS, NCH>(v.self, si, left);
+        }
     }
+#if defined(DOPF_STATS) || defined(DOPF_BLOCK_STAMPS)
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 8192 * 4) g_timeline[32768 + 2 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 // Warm start and, in the same block, the cold scan for what it left over: one launch for the storages of the big

@@ -7,15 +7,18 @@ pkg = dopf_pkg.load()
 from decentralopf_jl_amd import _capi, synth
 api = _capi.CApi("scripts/tmp/libdopf_stamps.so", "dopf_")      # product code + two stamps per block (-DDOPF_BLOCK_STAMPS)
 api.lib.dopf_debug_timeline.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32]
-pp = synth.baseline_config(2); A = pp.G + pp.S
-e = _capi.Engine(api, params=_capi.default_params(gamma=1.0 / A, eps=0.0, flags=_capi.F_NO_GRAPH), **pp.engine_kwargs())
-e.iterate(150)
+import bench
+wl = sys.argv[1] if len(sys.argv) > 1 else "config2"         # config2 (k_agents) or a network workload (k_net_agents)
+pp = bench.make_problem(synth, wl); A = pp.G + pp.S
+_capi._pin_hip_runtime()
+e = _capi.Engine(api, params=_capi.default_params(gamma=1.0 / A, w_flow=10.0 if pp.L == 0 else 0.3 / A, eps=0.0, flags=_capi.F_NO_GRAPH), **pp.engine_kwargs())
+e.iterate(300 if pp.L else 150)
 n = 8192 * 16
 buf = (C.c_uint64 * n)()
 assert api.lib.dopf_debug_timeline(e._ctx, buf, n) == 0
 tl = np.array(list(buf), dtype=np.float64)[32768:].reshape(-1, 2)
 tl = tl[(tl[:, 0] > 0) & (tl[:, 1] > 0)]
-nS = 569
+nS = int(sys.argv[2]) if len(sys.argv) > 2 else 569        # storage blocks in front of the grid
 t0 = tl[:, 0].min()
 us = lambda x: 10 * (x - t0) / 1e3
 sto, gen = tl[:nS], tl[nS:]
