@@ -23,7 +23,7 @@ for p in ("p1","p2"):
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
             cnt[(k, r["Counter_Name"])] += 1
         for k, d in agg.items():
-            if "k_sto" in k or "k_gen" in k or "k_reduce" in k or "k_agents" in k or "k_dual" in k:
+            if any(x in k for x in ("k_sto", "k_gen", "k_reduce", "k_agents", "k_net_agents", "k_slack", "k_dual")):
                 print(k, {c: round(v / cnt[(k, c)]) for c, v in d.items()})
                 summary.setdefault(k.split("::")[-1], {}).update({c: v / cnt[(k, c)] for c, v in d.items()})
                 summary[k.split("::")[-1]]["launches_averaged"] = max(cnt[(k, c)] for c in d)
