@@ -344,6 +344,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     // networks: generators and storages in one launch (k_net_agents) unless the storages run on a stream of their own
     v.genTT256 = std::max(1, std::min((std::min(T, 512) + 1) / 2, 256 / v.genR));
     v.fuseNet = (L > 0 && G > 0 && S > 0 && v.coldInWarm && !(c->q.flags & (DOPF_F_NO_FUSE | DOPF_F_OVERLAP_AGENTS)) &&
+                 v.genR * v.genTT256 <= 256 &&          // (T = 1: the 512-thread tiling has more agent lanes than such a block has threads)
                  !getenv("DOPF_NO_NET_FUSE")) ? 1 : 0;
 
     // sort agents by node (stable), remember the permutation
