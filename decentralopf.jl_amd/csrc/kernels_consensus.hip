@@ -1123,9 +1123,8 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
 {
     const int halt = UPDATE ? v.st->halt : 0;           // (looked at once the first loads are on their way; nothing stored before)
     const StatusPre spre = UPDATE ? status_load(v) : StatusPre{0, 0, 0};       // (what the stop test starts from: loaded now, used at the end)
-    const int tid0_ = threadIdx.x, t0_ = blockIdx.x;
-#ifdef DOPF_DUAL_STAMPS
-    if (UPDATE && tid0_ == 0 && t0_ == v.T / 2) v.st->dbg_reason[0] = wall_clock64();
+#ifdef DOPF_DUAL_STAMPS          // (measurement build: wall-clock stamps of block T/2's phases in the status block's counters, scripts/dual_stamps.py)
+    if (UPDATE && threadIdx.x == 0 && (int)blockIdx.x == v.T / 2) v.st->dbg_reason[0] = wall_clock64();
 #endif
     extern __shared__ double sh[];               // q[N] injections | d[L] mu - rho | G[L] | S[L]
     __shared__ double red[3][1024];
