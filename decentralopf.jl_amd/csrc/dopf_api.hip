@@ -298,12 +298,9 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
 #define TRY(x) do { rc = (x); if (rc) return bail(rc); } while (0)
 #define HIPTRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(c, DOPF_E_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); return bail(DOPF_E_DEVICE); } } while (0)
 
-    // Big networks: the generator sweep (HBM bound at this size) and the storage solve (fp64 VALU bound) are long enough for a
-    // second stream to pay (configs[3] at full size on one GPU: 145 -> 136 us per iteration; the fork and join cost ~5 us, the
-    // 1/8 share with its 12 us kernels loses 5 us to them, a copper plate loses its one-launch iteration)
-    if (p->L > 0 && (long long)p->G * p->T >= (6ll << 20) && (long long)p->S * p->T >= (1ll << 19) && !q->stream &&
-        !(q->flags & DOPF_F_NO_FUSE) && !getenv("DOPF_NO_AUTO_OVERLAP"))
-        c->q.flags |= DOPF_F_OVERLAP_AGENTS;
+    // (Round 3 ran big networks — configs[3] at full size — with the storage solve on a second stream by itself: 145 -> 136 us per
+    // iteration. With generators and storages in one launch whose generator blocks work on both column halves at once
+    // (k_net_agents) the one-stream form is ahead again, 117.8 vs 124.9 us; DOPF_F_OVERLAP_AGENTS stays for whoever asks.)
     if (q->stream) { c->main = (hipStream_t)q->stream; c->own_main = false; }
     else { HIPTRY(hipStreamCreateWithFlags(&c->main, hipStreamNonBlocking)); c->own_main = true; }
     // the side stream exists only when it is used: HIP maps streams onto a few hardware queues (4 by default), and a
