@@ -560,7 +560,7 @@ def main():
             # of an empty pair's cost overlaps with a real kernel's own launch). The overhead used here is the one that makes
             # the kernels of an iteration ADD UP to the per-iteration time of the graph replay (no events in there): live,
             # no constant. rocprofv3's per-kernel durations agree with it (profiles/).
-            launched = ["gen_ms"] + ([] if fused else ["sto_ms"]) + (["slack_ms"] if pp.L > 0 else []) + \
+            launched = ["gen_ms"] + ([] if fused else ["sto_ms"]) + (["slack_ms"] if pp.L > 0 and not timing.get("quiet") else []) + \
                        (["tables_ms"] if pp.L > 0 and timing["tables_ms"] > 1.5 * timing["empty_ms"] else []) + \
                        ([] if tail else ([] if timing.get("slack_in_dual") else ["reduce_ms"]) + ["dual_ms"])
 

@@ -47,7 +47,7 @@ class DopfTiming(C.Structure):
                 ("slack_ms", C.c_double), ("reduce_ms", C.c_double), ("dual_ms", C.c_double),
                 ("iter_ms", C.c_double), ("empty_ms", C.c_double), ("iters", C.c_int32),
                 ("agents_fused", C.c_int32), ("tail_fused", C.c_int32),
-                ("slack_in_dual", C.c_int32), ("reserved_", C.c_int32)]
+                ("slack_in_dual", C.c_int32), ("quiet", C.c_int32)]
 
 
 class DopfCentralResult(C.Structure):

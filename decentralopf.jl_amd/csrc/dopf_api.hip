@@ -127,12 +127,13 @@ static bool tail_fused(const dopf_ctx *c, bool single)
     return single && c->v.tailDev != nullptr && (c->comm == nullptr || c->tail_xchg);
 }
 
-void enqueue_local(dopf_ctx *c, bool single)
+void enqueue_local(dopf_ctx *c, bool single, bool quiet)
 {
     DevView v = c->v;
     v.sliceDual = slice_dual(v, single) ? 1 : 0;
     v.tail = tail_fused(c, single) ? v.tailDev : nullptr;
     v.slackInDual = single && v.slackDualOk;
+    v.quiet = v.slackInDual && quiet;
     launch_tables(v, c->main);
     const bool fork = v.nGenItems > 0 && v.nStoItems > 0 && (c->q.flags & DOPF_F_OVERLAP_AGENTS);
     if (v.fuseAgents) {
@@ -151,16 +152,17 @@ void enqueue_local(dopf_ctx *c, bool single)
         launch_sto_update(v, c->lc, c->main);
     }
     if (v.tail) return;                    // sums, dual step and stop test happened in the launch above
-    launch_slack(v, c->main);
+    if (!v.quiet) launch_slack(v, c->main);
     if (!v.slackInDual) launch_reduce(v, c->main);
 }
 
-void enqueue_apply(dopf_ctx *c, bool single, const XchgView *xd)
+void enqueue_apply(dopf_ctx *c, bool single, const XchgView *xd, bool quiet)
 {
     if (tail_fused(c, single)) return;
     DevView v = c->v;
     v.sliceDual = slice_dual(v, single) ? 1 : 0;
     v.slackInDual = single && v.slackDualOk;
+    v.quiet = v.slackInDual && quiet;
     launch_dual(v, c->main, xd);
 }
 
@@ -169,8 +171,11 @@ void drop_graphs(dopf_ctx *c)
     if (c->graph1) hipGraphExecDestroy(c->graph1);
     if (c->graphM) hipGraphExecDestroy(c->graphM);
     if (c->graphU) hipGraphExecDestroy(c->graphU);
-    c->graph1 = c->graphM = c->graphU = nullptr;
-    c->graphs_valid = false;
+    if (c->graph1q) hipGraphExecDestroy(c->graph1q);
+    if (c->graphMq) hipGraphExecDestroy(c->graphMq);
+    if (c->graphUq) hipGraphExecDestroy(c->graphUq);
+    c->graph1 = c->graphM = c->graphU = c->graph1q = c->graphMq = c->graphUq = nullptr;
+    c->graphs_valid = c->graphs_q_valid = false;
 }
 
 int read_status(dopf_ctx *c)
@@ -195,27 +200,27 @@ namespace {
 
 // one iteration of the chain on the context's stream; a sharded context (dopf_comm_init) puts the all-reduce
 // of the consensus buffer between the local sums and the dual step
-int enqueue_iteration(dopf_ctx *c)
+int enqueue_iteration(dopf_ctx *c, bool quiet = false)
 {
     const bool single = c->comm == nullptr;
     // copper plate + peer exchange: the one-block dual kernel exchanges the vector itself — the single-GPU chain, no extra launch
     const XchgView *xd = comm_xchg(c);
     if (xd && !(c->v.L == 0 && slice_dual(c->v, true)) && !c->tail_xchg) xd = nullptr;
     const bool like_single = single || xd != nullptr;        // (tail_xchg: the launch's tail block exchanges; nothing else is launched)
-    enqueue_local(c, like_single);
+    enqueue_local(c, like_single, quiet && single);
     if (!like_single) { const int rc = comm_enqueue_allreduce(c); if (rc) return rc; }
-    enqueue_apply(c, like_single, xd);
+    enqueue_apply(c, like_single, xd, quiet && single);
     return DOPF_OK;
 }
 
-int build_graph(dopf_ctx *c, int iters, hipGraphExec_t *out)
+int build_graph(dopf_ctx *c, int iters, hipGraphExec_t *out, bool quiet = false)
 {
     hipGraph_t g = nullptr;
     // (a sharded context captures the RCCL collective with the kernels; thread-local mode keeps the capture
     // from tripping over what other host threads — other GPUs' drivers — do meanwhile)
     HIPCHK(c, hipStreamBeginCapture(c->main, c->comm ? hipStreamCaptureModeThreadLocal : hipStreamCaptureModeRelaxed));
     int rc = DOPF_OK;
-    for (int i = 0; i < iters && rc == DOPF_OK; ++i) rc = enqueue_iteration(c);
+    for (int i = 0; i < iters && rc == DOPF_OK; ++i) rc = enqueue_iteration(c, quiet);
     const hipError_t ec = hipStreamEndCapture(c->main, &g);
     if (rc) { if (g) hipGraphDestroy(g); return rc; }
     if (ec != hipSuccess) return fail(c, DOPF_E_DEVICE, "hipStreamEndCapture: %s", hipGetErrorString(ec));
@@ -521,6 +526,8 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         // k_reduce launch (the chain a sharded context runs: bitwise comparisons against it)
         v.slackDualOk = L > 0 && L <= 256 && N <= 256 && n1 > kSmallConsensus && !v.splitDual && !(q->flags & DOPF_F_NO_TAIL_FUSE) &&
                         !getenv("DOPF_REDUCE_LAUNCH");
+        // ... and, while no line is flagged, the node sums too (the quiet chain: no k_slack launch; DevView::quiet, dopf_iterate)
+        c->quiet_ok = v.slackDualOk && !(q->flags & DOPF_F_KEEP_DELTAS) && !getenv("DOPF_NO_QUIET");
     }
     double *cons = nullptr;
     TRY(dev_alloc(c, &cons, NT + 2 * LT + 1));
@@ -604,18 +611,39 @@ int dopf_iterate(dopf_ctx *c, int32_t n_iters, int32_t *iters_done, int32_t *con
     while (left > 0) {
         int slice = std::min(left, kCheckEvery);
         left -= slice;
+        // the quiet chain (networks, no line flagged at the last look: no k_slack launch) has graphs of its own, built when first used
+        bool quiet = c->quiet_ok && c->quiet && c->comm == nullptr;
+        if (quiet && !eager && !c->graphs_q_valid) {
+            int rc = build_graph(c, 1, &c->graph1q, true);
+            if (rc == DOPF_OK) rc = build_graph(c, kMid, &c->graphMq, true);
+            if (rc == DOPF_OK) rc = build_graph(c, kUnroll, &c->graphUq, true);
+            if (rc) return rc;
+            c->graphs_q_valid = true;
+        }
+        const int asked = slice, total_before = c->host_st.iters_total;
         if (eager) {
-            for (int i = 0; i < slice; ++i) { const int rc = enqueue_iteration(c); if (rc) return rc; }
+            for (int i = 0; i < slice; ++i) { const int rc = enqueue_iteration(c, quiet); if (rc) return rc; }
         } else {
-            for (; slice >= kUnroll; slice -= kUnroll) HIPCHK(c, hipGraphLaunch(c->graphU, c->main));
-            for (; slice >= kMid; slice -= kMid) HIPCHK(c, hipGraphLaunch(c->graphM, c->main));
-            for (; slice > 0; --slice) HIPCHK(c, hipGraphLaunch(c->graph1, c->main));
+            for (; slice >= kUnroll; slice -= kUnroll) HIPCHK(c, hipGraphLaunch(quiet ? c->graphUq : c->graphU, c->main));
+            for (; slice >= kMid; slice -= kMid) HIPCHK(c, hipGraphLaunch(quiet ? c->graphMq : c->graphM, c->main));
+            for (; slice > 0; --slice) HIPCHK(c, hipGraphLaunch(quiet ? c->graph1q : c->graph1, c->main));
         }
         HIPCHK(c, hipGetLastError());
         if (timed && left == 0) HIPCHK(c, hipEventRecord(c->evT1, c->main));
         const int rc = read_status(c);
         if (rc) return rc;
+        if (c->host_st.halt == 2) {
+            // the quiet chain parked itself: its last dual step flagged a line, the iterations behind it were no-ops. Release the
+            // device, go back to the chain with k_slack and feed what is left of the slice again.
+            HIPCHK(c, hipMemsetAsync(&c->v.st->halt, 0, sizeof(int), c->main));
+            c->host_st.halt = 0;
+            c->quiet = false;
+            ++c->quiet_parked;
+            left += asked - (c->host_st.iters_total - total_before);
+            continue;
+        }
         if (c->host_st.halt) break;
+        c->quiet = c->quiet_ok && c->host_st.walk_last == 0;
     }
     c->last_call_ms = -1.0;
     if (timed && left == 0) {
@@ -639,6 +667,7 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
     v.sliceDual = slice_dual(v, true) ? 1 : 0;
     v.tail = tail_fused(c, true) ? v.tailDev : nullptr;
     v.slackInDual = v.slackDualOk;
+    v.quiet = v.slackInDual && c->quiet_ok && c->quiet;        // (the chain dopf_iterate would launch now)
     enum { E_T0, E_T1, E_G0, E_G1, E_S0, E_S1, E_K0, E_K1, E_R1, E_D1, E_X0, E_X1, E_N };
     struct Events {                                     // destroyed on every way out
         std::vector<hipEvent_t> v;
@@ -665,7 +694,7 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
         hipEventRecord(e[E_S1], ss);
         if (fork) { hipEventRecord(c->evJoin, c->side); hipStreamWaitEvent(c->main, c->evJoin, 0); }
         hipEventRecord(e[E_K0], c->main);
-        if (!v.tail) launch_slack(v, c->main);
+        if (!v.tail && !v.quiet) launch_slack(v, c->main);
         hipEventRecord(e[E_K1], c->main);
         if (!v.tail && !v.slackInDual) launch_reduce(v, c->main);
         hipEventRecord(e[E_R1], c->main);
@@ -677,6 +706,14 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
     HIPCHK(c, hipGetLastError());
     int rc = read_status(c);
     if (rc) return rc;
+    if (c->host_st.halt == 2) {            // the quiet chain parked itself inside the timed iterations (the ones behind were no-ops)
+        HIPCHK(c, hipMemsetAsync(&c->v.st->halt, 0, sizeof(int), c->main));
+        c->host_st.halt = 0;
+        c->quiet = false;
+        ++c->quiet_parked;
+    } else if (!c->host_st.halt) {
+        c->quiet = c->quiet_ok && c->host_st.walk_last == 0;
+    }
     if (c->side) HIPCHK(c, hipStreamSynchronize(c->side));
     memset(out, 0, sizeof *out);
     auto ms = [&](hipEvent_t a, hipEvent_t b) { float f = 0.f; hipEventElapsedTime(&f, a, b); return (double)f; };
@@ -698,6 +735,7 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
     out->agents_fused = v.fuseAgents || v.fuseNet;
     out->tail_fused = v.tail ? 1 : 0;
     out->slack_in_dual = (!v.tail && v.slackInDual) ? 1 : 0;
+    out->quiet = v.quiet ? 1 : 0;
     return DOPF_OK;
 }
 
@@ -914,6 +952,7 @@ int dopf_set_state(dopf_ctx *c, const double *P, const double *D, const double *
         std::vector<int> mixed(v.G, 2);
         HIPCHK(c, hipMemcpy(v.gen_state, mixed.data(), sizeof(int) * v.G, hipMemcpyHostToDevice));
     }
+    c->quiet = false;                      // (flags are formed anew from the state handed in)
     Status st{};
     HIPCHK(c, hipMemcpy(&st, v.st, sizeof st, hipMemcpyDeviceToHost));
     st.iteration = iteration;
@@ -1054,6 +1093,13 @@ int dopf_debug_stats(dopf_ctx *c, uint64_t *out3 /* 15 values */)
     }
     for (int i = 0; i < 4; ++i) out3[5 + i] = c->host_st.dbg_reason[i];
     for (int i = 0; i < 6; ++i) out3[9 + i] = c->host_st.dbg_cyc[i];
+    return DOPF_OK;
+}
+
+int dopf_debug_quiet(dopf_ctx *c, int64_t *out3)
+{
+    if (!c || !out3) return DOPF_E_INVALID;
+    out3[0] = c->quiet_ok ? 1 : 0; out3[1] = c->quiet ? 1 : 0; out3[2] = (int64_t)c->quiet_parked;
     return DOPF_OK;
 }
 

@@ -20,6 +20,13 @@ struct dopf_ctx {
     double last_call_ms = -1.0;
     hipGraphExec_t graph1 = nullptr, graphM = nullptr, graphU = nullptr;   // 1, kMid, kUnroll iterations per launch
     bool graphs_valid = false;
+    // Networks on the three-launch chain: while no line is flagged (Status::walk_last == 0 at the last look) the "quiet" chain runs —
+    // k_net_agents and the dual/price kernel, which forms the node sums itself; k_slack is not launched. Graphs of its own.
+    hipGraphExec_t graph1q = nullptr, graphMq = nullptr, graphUq = nullptr;
+    bool graphs_q_valid = false;
+    bool quiet_ok = false;          // the problem, the flags and the environment allow the quiet chain
+    bool quiet = false;             // the next launches may use it
+    unsigned long long quiet_parked = 0;    // times the quiet chain parked itself (a line got flagged) and the host went back
     std::vector<void *> allocs;
     void *own_cons = nullptr;
     std::vector<int> gen_perm, sto_perm;   // sorted position -> caller's index
@@ -36,8 +43,8 @@ namespace dopf {
 
 int fail(dopf_ctx *c, int code, const char *fmt, ...);
 void keep_error(const dopf_ctx *c);          // the context's message becomes what dopf_last_error(NULL) returns
-void enqueue_local(dopf_ctx *c, bool single);
-void enqueue_apply(dopf_ctx *c, bool single, const XchgView *xd = nullptr);
+void enqueue_local(dopf_ctx *c, bool single, bool quiet = false);
+void enqueue_apply(dopf_ctx *c, bool single, const XchgView *xd = nullptr, bool quiet = false);
 void drop_graphs(dopf_ctx *c);
 int read_status(dopf_ctx *c);
 // dopf_comm.hip

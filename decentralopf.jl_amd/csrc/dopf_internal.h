@@ -40,6 +40,7 @@ struct Status {
     unsigned long long resbits[3];   // running max of |dual change| as bit patterns (>= 0 doubles)
     unsigned long long resbits2[2][3];   // k_dual_price_t1024: the same, one set per iteration parity (the stop test does not read them:
                                          // its ticket word carries "some residual >= eps"); the host decodes the reported set
+    int walk_last;                  // k_dual_price_t1024: timesteps for which the last dual step flagged a line (k_slack has agents to walk in the next iteration)
     int res_set;                    // -1: res[] holds the residuals of the last checked iteration; 0/1: resbits2[res_set] does
     double res[3];          // lambda / mu / rho residual inf-norms of the last checked iteration
     double total_cost;
@@ -83,6 +84,8 @@ struct DevView {
                                     // sums and the cost itself, the dual/price block of timestep t forms the slack sums of its lines from the
                                     // PTDF rows it reads anyway — no k_reduce launch
     int slackDualOk;                // the problem and the flags allow that
+    int quiet;                      // per launch (with slackInDual): the quiet chain — no line is flagged, k_slack is not launched, the dual/price
+                                    // kernel forms the node sums too
     int genTT256;                   // networks, fused launch: column tiling of a 256-thread generator block with the same R as genR
     int fuseNet;                    // networks: generators + storages in one launch (k_net_agents), single-GPU chain
     int fuseAgents;                 // copper plate, even T: generators + storages in one launch (k_agents, 256-thread blocks)

@@ -1118,7 +1118,12 @@ __global__ __launch_bounds__(256) void k_price_t(DevView v)
 // line state is on its way while the flows are formed, mu - rho and the G / S terms of the linear pieces go from the
 // dual half to the price half through LDS, and the residual maxima meet in a ticket: the block that finishes last runs
 // the stop test (one atomic round trip per block instead of a launch). Every sum has a fixed order.
-template <bool UPDATE, bool SID = false>
+// QUIET (with SID; the host's "quiet" chain, dopf_api.hip): no line of any timestep is flagged, so k_slack has nothing to walk and
+// is not launched — the block forms the nodes' sums of its timestep itself, from the items' partial rows (one 8-byte read per
+// row: 76 KB of sectors per block on the 118-node share, one round trip), with k_slack's arithmetic and bits. If the dual step
+// flags a line for the NEXT iteration the last block parks the chain (Status::halt = 2) and the host goes back to the chain
+// with k_slack.
+template <bool UPDATE, bool SID = false, bool QUIET = false>
 __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
 {
     const int halt = UPDATE ? v.st->halt : 0;           // (looked at once the first loads are on their way; nothing stored before)
@@ -1147,18 +1152,74 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
     const size_t i = (size_t)(l < L ? l : 0) + (size_t)L * t;
     const int Nc = (((N + 3) / 4) + 7) & ~7, nbeg = pl * Nc, nend = min(N, nbeg + Nc);
     const bool mine = sid && l < L && nbeg < nend;           // this thread forms a part of the slack sums of line l
+    // QUIET: the thread's first batch of PTDF rows depends on nothing the kernel computes — issued here, it arrives while the nodes'
+    // sums are formed (two dependent round trips). (Not in the other variants: there the registers cost more than the wait.)
+    double h0[kFlight];
+    if (QUIET) {
+#pragma unroll
+        for (int u = 0; u < kFlight; ++u) h0[u] = (l < L && nbeg + u < nend) ? v.ptdf[l + (size_t)L * (nbeg + u)] : 0.0;
+    }
     double f_old = 0.0, aU_old = 0.0, aK_old = 0.0, F = 0.0, cntp = 0.0;
     int wf = 0;
     if (lt || mine) {                            // (in flight while the flows are formed)
         f_old = v.flow[i]; aU_old = v.avgU[i]; aK_old = v.avgK[i]; F = v.fmax[l];
     }
     if (mine) {
-        wf = v.walk_flag[i];
+        wf = QUIET ? 0 : v.walk_flag[i];
         cntp = (double)((v.node_gen_beg[nend] - v.node_gen_beg[nbeg]) + (v.node_sto_beg[nend] - v.node_sto_beg[nbeg]));   // agents at the part's nodes
     }
     const double lam_old = v.lam[t], s_old = v.s[t];
-    double x = 0.0;
-    if (tid < N) {
+    double x = 0.0, cost_q = 0.0;
+    if (QUIET) {
+        // node sums of timestep t: thread (node, lane r of eight), rows r, r + 8, ... of the node (rows_sum: k_slack's order),
+        // the eight lanes added in lane order; 128 nodes per pass
+        for (int nb = 0; nb < N; nb += 128) {
+            const int n = nb + (tid >> 3), r = tid & 7;
+            double acc = 0.0, was = 0.0, dem = 0.0;
+            if (n < N) {
+                const int g0 = v.node_gitem_beg[n], ngi = v.node_gitem_beg[n + 1] - g0, s0 = v.node_sitem_beg[n], nsi = v.node_sitem_beg[n + 1] - s0;
+                if (r == 0) { was = v.prev_node[n + (size_t)N * t]; dem = v.demand[n + (size_t)N * t]; }
+                acc = rows_sum(v, g0, ngi, s0, nsi, 0, ngi + 2 * nsi, r, t);
+            }
+            red[0][tid] = acc;
+            __syncthreads();
+            if (halt) return;                            // (uniform; nothing has been stored)
+            if (n < N && r == 0) {
+                double sn = 0.0;
+                for (int k = 0; k < 8; ++k) sn += red[0][tid + k];
+                const size_t at = n + (size_t)N * t;
+                sdL[n] = sn - was;
+                q[n] = sn - dem;                                             // results.jl:58-100
+                v.prev_node[at] = sn; v.node_dsum[at] = sn - was; v.cons[at] = sn;
+            }
+            __syncthreads();
+        }
+        if (t == 0) {                                    // the cost, by the block of the first timestep (k_slack's order)
+            const int ngr = v.genRows > 0 ? v.genRows : v.nGenItems, nc = ngr + v.nStoItems;
+            double c = 0.0;
+            if (tid < 256)
+                for (int k0 = tid; k0 < nc; k0 += 8 * 256) {          // eight items' costs in flight per lane, added in item order
+                    double xc[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int k = k0 + 256 * u < nc ? k0 + 256 * u : k0;
+                        xc[u] = k < ngr ? v.part_gcost[k] : v.part_scost[k - ngr] + v.part_scost_w[k - ngr];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) c += k0 + 256 * u < nc ? xc[u] : 0.0;
+                }
+            if (tid < 256) red[0][tid] = c;
+            __syncthreads();
+            for (int sft = 128; sft > 0; sft >>= 1) {
+                if (tid < sft) red[0][tid] += red[0][tid + sft];
+                __syncthreads();
+            }
+            cost_q = red[0][0];
+            __syncthreads();
+            if (tid == 0) v.cons[NT + 2 * LT] = cost_q;
+        }
+        if (tid < N) x = q[tid];
+    } else if (tid < N) {
         x = cinj[tid + (size_t)N * t] - v.demand[tid + (size_t)N * t];       // results.jl:58-100
         q[tid] = x;
         if (sid) sdL[tid] = v.node_dsum[tid + (size_t)N * t];
@@ -1168,13 +1229,13 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         for (int d = 32; d > 0; d >>= 1) ps += __shfl_xor(ps, d);
         if (lane == 0 && tid < 256) wsum[tid >> 6] = ps;
     }
-    const int anyWalk = sid ? __syncthreads_or(wf) : (__syncthreads(), 0);
+    const int anyWalk = (sid && !QUIET) ? __syncthreads_or(wf) : (__syncthreads(), 0);
 
 #ifdef DOPF_DUAL_STAMPS
     if (UPDATE && tid == 0 && t == T / 2) v.st->dbg_reason[1] = wall_clock64();
 #endif
     if (halt) return;                                    // (uniform)
-    if (sid && anyWalk) {
+    if (sid && !QUIET && anyWalk) {
         // (rare, uniform) a line of t has its switch point inside some node's window: the parts of those lines' sums, node
         // by node, before anything else is held in registers
         if (tid < N) {
@@ -1205,11 +1266,8 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         if (!sid) { sU = cU[i]; sK = cK[i]; }
     }
     double f = 0.0, ds = 0.0;
-    if (l < L)
-        for (int n0 = nbeg; n0 < nend; n0 += kFlight) {                        // kFlight rows of ptdf in flight
-            double h[kFlight];
-#pragma unroll
-            for (int u = 0; u < kFlight; ++u) h[u] = n0 + u < nend ? v.ptdf[l + (size_t)L * (n0 + u)] : 0.0;
+    if (l < L) {
+        auto use = [&](const double (&h)[kFlight], int n0) {
 #pragma unroll
             for (int u = 0; u < kFlight; ++u) f += h[u] * (n0 + u < nend ? q[n0 + u] : 0.0);
             if (sid) {
@@ -1217,7 +1275,15 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
                 for (int u = 0; u < kFlight; ++u)
                     if (n0 + u < nend) ds = fma(h[u], sdL[n0 + u], ds);
             }
+        };
+        if (QUIET) use(h0, nbeg);                                              // (on its way since the kernel's entry)
+        for (int n0 = QUIET ? nbeg + kFlight : nbeg; n0 < nend; n0 += kFlight) {      // kFlight rows of ptdf in flight
+            double h[kFlight];
+#pragma unroll
+            for (int u = 0; u < kFlight; ++u) h[u] = n0 + u < nend ? v.ptdf[l + (size_t)L * (n0 + u)] : 0.0;
+            use(h, n0);
         }
+    }
 
 #ifdef DOPF_DUAL_STAMPS
     if (UPDATE && tid == 0 && t == T / 2) v.st->dbg_reason[2] = wall_clock64();
@@ -1338,7 +1404,7 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         viol_ = (rl < v.eps && bm < v.eps && br < v.eps) ? 0ull : 1ull;               // convergence.jl:15-23
         int zero;
         asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
-        tk_ = atomicAdd(v.dual_ticket + zero, 1ull | (viol_ << 32));
+        tk_ = atomicAdd(v.dual_ticket + zero, 1ull | (viol_ << 32) | ((unsigned long long)(anyNeed ? 1 : 0) << 48));
     }
     red[0][tid] = pr; red[1][tid] = psx; red[2][tid] = sl;
     __syncthreads();
@@ -1375,7 +1441,7 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
 #endif
     if (UPDATE && tid == 0) {
         // Stop test, part 2: whoever drew the last ticket has every block's verdict in the word it got back
-        if (t == 0) v.st->total_cost = v.cons[NT + 2 * LT];
+        if (t == 0) v.st->total_cost = QUIET ? cost_q : v.cons[NT + 2 * LT];
         const bool last_ = (unsigned)(tk_ & 0xffffffffull) == (unsigned)(T - 1);
 #ifdef DOPF_DUAL_STAMPS
         if (t == T / 2) v.st->dbg_cyc[4] = wall_clock64();        // (the ticket has returned)
@@ -1387,14 +1453,18 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
             *v.dual_ticket = 0ull;
             int conv = spre.converged, it = spre.iteration;
             if (it != 1) {                                                        // convergence.jl:3
-                conv = (tk_ >> 32) + viol_ == 0ull;
+                conv = ((tk_ >> 32) & 0xffffull) + viol_ == 0ull;
                 st->converged = conv;
                 st->res_set = par;
             }
             st->iters_total = spre.iters_total + 1;
             if (!conv) it += 1;                                                   // convergence.jl:25-30
             st->iteration = it;
-            st->halt = conv || (v.max_iters > 0 && it > v.max_iters);
+            // timesteps with a flagged line for the next iteration: the quiet chain cannot run it (halt = 2: parked, not finished)
+            const int walks = (int)(tk_ >> 48) + (anyNeed ? 1 : 0);
+            st->walk_last = walks;
+            const int stop = conv || (v.max_iters > 0 && it > v.max_iters);
+            st->halt = stop ? 1 : ((QUIET && walks > 0) ? 2 : 0);
         }
     }
 }
@@ -1610,6 +1680,7 @@ static size_t t1024_lds(const DevView &v)
     if (bytes > 48 * 1024 && !raised) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_dual_price_t1024<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_dual_price_t1024<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_dual_price_t1024<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_dual_price_t1024<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         raised = true;
     }
@@ -1626,7 +1697,8 @@ void launch_dual(const DevView &v, hipStream_t s, const XchgView *xd)
         return;
     }
     if (v.L > 0 && v.L <= 256 && v.N <= 256 && !v.splitDual) {
-        if (v.slackInDual) hipLaunchKernelGGL((k_dual_price_t1024<true, true>), dim3(v.T), dim3(1024), t1024_lds(v), s, v);
+        if (v.slackInDual && v.quiet) hipLaunchKernelGGL((k_dual_price_t1024<true, true, true>), dim3(v.T), dim3(1024), t1024_lds(v), s, v);
+        else if (v.slackInDual) hipLaunchKernelGGL((k_dual_price_t1024<true, true>), dim3(v.T), dim3(1024), t1024_lds(v), s, v);
         else hipLaunchKernelGGL(k_dual_price_t1024<true>, dim3(v.T), dim3(1024), t1024_lds(v), s, v);
         return;
     }

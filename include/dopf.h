@@ -216,7 +216,8 @@ typedef struct dopf_timing {
                                dual_ms are empty event pairs */
     int32_t slack_in_dual;  /* 1 (networks): node sums left from k_slack, slack sums were formed by the dual/price kernel:
                                reduce_ms is an empty event pair */
-    int32_t reserved_;
+    int32_t quiet;          /* 1 (networks): no line was flagged, k_slack was not launched (slack_ms is an empty event pair): the dual/price
+                               kernel formed the node sums too */
 } dopf_timing;
 int dopf_iterate_timed(dopf_ctx *ctx, int32_t n_iters, dopf_timing *out);
 /* DOPF_F_TIME_CALLS: milliseconds between the first launch of the last dopf_iterate call and the end of its last one, on the
@@ -297,6 +298,9 @@ dopf_ctx *dopf_multi_ctx(dopf_multi *m, int32_t i);
 int dopf_debug_stats(dopf_ctx *ctx, uint64_t *out15);
 /* Diagnostics (-DDOPF_STATS builds; -1 otherwise): 8 wall-clock stamps (100 MHz) per wave of the storage body's last launch. */
 int dopf_debug_timeline(dopf_ctx *ctx, uint64_t *out, int32_t n);
+/* networks: out3 = { the quiet chain (no k_slack launch while no line is flagged) is allowed for this context, the next launches
+ * would use it, times it parked itself because a line got flagged and the host went back to the chain with k_slack } */
+int dopf_debug_quiet(dopf_ctx *ctx, int64_t *out3);
 /* Diagnostics (L > 0): the breakpoint table of node n, timestep t that the last x-update used:
  * beta, psi: 2L doubles (first *m valid, ascending), slope: 2L+1, psi0 = Psi(0). */
 int dopf_debug_table(dopf_ctx *ctx, int32_t n, int32_t t, double *beta, double *psi, double *slope,

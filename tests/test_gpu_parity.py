@@ -420,6 +420,24 @@ def test_hip_slack_sums_in_the_dual_launch_are_bit_identical(hip_api, monkeypatc
                 assert np.array_equal(sa[k], sb[k]), (n, k, float(np.abs(sa[k] - sb[k]).max()))
     assert a.solver_failures() == 0 and b.solver_failures() == 0
     assert np.abs(sa["avg_U"]).max() > 0 or np.abs(sa["avg_K"]).max() > 0 or wf is not None
+    # the quiet chain (no k_slack launch while no line is flagged): allowed on a, never on b; with the scaled flow weight the flags are
+    # gone by now and a runs it — more single iterations, so that a line flagged again parks it in front of the host's eyes
+    import ctypes as C
+    qa, qb = (C.c_int64 * 3)(), (C.c_int64 * 3)()
+    assert hip_api.lib.dopf_debug_quiet(a._ctx, qa) == 0 and hip_api.lib.dopf_debug_quiet(b._ctx, qb) == 0
+    assert qa[0] == 1 and qb[0] == 0 and qb[1] == 0 and qb[2] == 0
+    for n in (1, 1, 2, 7, 16, 33):
+        a.iterate(n)
+        b.iterate(n)
+        sa, sb = state_of(a), state_of(b)
+        for k in sa:
+            if k != "cost" and sa[k].size:
+                assert np.array_equal(sa[k], sb[k]), ("quiet", n, k)
+        assert a.get_residuals() == b.get_residuals()
+    hip_api.lib.dopf_debug_quiet(a._ctx, qa)
+    print(name, "quiet at the end:", qa[1], "parked:", qa[2])
+    if wf is not None and "118" in name:
+        assert qa[1] == 1
 
 
 def test_hip_row_skipping_is_bit_identical(hip_api):
