@@ -388,6 +388,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         tvh.scaleCost = std::ldexp(1.0, std::max(0, std::min(kc, 60))); tvh.invCost = 1.0 / tvh.scaleCost;
     }
     std::vector<Item> gitems, sitems;
+    int max_node_rows = 1;
     std::vector<int> ngb, nsb, ngib, nsib;
     {
         const int R = v.genTT2 ? v.genR2 : v.genR;
@@ -432,6 +433,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         int max_items = 1;
         for (int n = 0; n < N; ++n)      // storage items: scan + warm rows; generators: items, or (one node, streaming) blocks
             max_items = std::max(max_items, (v.genRows > 0 ? v.genRows : ngib[n + 1] - ngib[n]) + 2 * (nsib[n + 1] - nsib[n]));
+        max_node_rows = max_items;
         v.reduceRB = std::max(1, std::min(64, (max_items + 31) / 32));
         // Networks: nodes x timestep chunks already give hundreds of blocks, and more than one block per node means the
         // two-level sum — an agent-scope release (a write-back of the XCD's L2) and a ticket in EVERY block. configs[3] at full
@@ -527,7 +529,10 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         v.slackDualOk = L > 0 && L <= 256 && N <= 256 && n1 > kSmallConsensus && !v.splitDual && !(q->flags & DOPF_F_NO_TAIL_FUSE) &&
                         !getenv("DOPF_REDUCE_LAUNCH");
         // ... and, while no line is flagged, the node sums too (the quiet chain: no k_slack launch; DevView::quiet, dopf_iterate)
-        c->quiet_ok = v.slackDualOk && !(q->flags & DOPF_F_KEEP_DELTAS) && !getenv("DOPF_NO_QUIET");
+        // (up to 32 rows per node — one batch of the eight lanes' four loads; configs[3] at full size has 36, and there the node sums
+        // cost the dual kernel what k_slack and its boundary cost: 119.3 us per iteration either way)
+        c->quiet_ok = v.slackDualOk && !(q->flags & DOPF_F_KEEP_DELTAS) && (max_node_rows <= 32 || getenv("DOPF_QUIET_ANY_SIZE")) &&
+                      !getenv("DOPF_NO_QUIET");
     }
     double *cons = nullptr;
     TRY(dev_alloc(c, &cons, NT + 2 * LT + 1));
