@@ -529,8 +529,8 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         v.slackDualOk = L > 0 && L <= 256 && N <= 256 && n1 > kSmallConsensus && !v.splitDual && !(q->flags & DOPF_F_NO_TAIL_FUSE) &&
                         !getenv("DOPF_REDUCE_LAUNCH");
         // ... and, while no line is flagged, the node sums too (the quiet chain: no k_slack launch; DevView::quiet, dopf_iterate)
-        // (up to 32 rows per node — one batch of the eight lanes' four loads; configs[3] at full size has 36, and there the node sums
-        // cost the dual kernel what k_slack and its boundary cost: 119.3 us per iteration either way)
+        // (up to 32 rows per node: one batch of the eight lanes' four loads. configs[3] at full size has 25 and is where the gain
+        // ends — the node sums cost the dual kernel what k_slack and its boundary cost, 119.3 us per iteration either way)
         c->quiet_ok = v.slackDualOk && !(q->flags & DOPF_F_KEEP_DELTAS) && (max_node_rows <= 32 || getenv("DOPF_QUIET_ANY_SIZE")) &&
                       !getenv("DOPF_NO_QUIET");
     }
