@@ -40,6 +40,17 @@ def test_struct_layouts_match_the_header():
     q = _capi.DopfParams()
     ctypes.CDLL(_capi.HIP_LIB_PATH).dopf_default_params(ctypes.byref(q))
     assert (q.gamma, q.w_flow, q.w_prox, q.eps, q.mask_thr, q.device) == (0.3, 10.0, 1.0, 1e-3, 1e-2, -1)
+    # dopf_timing and dopf_central_result: the ctypes mirrors name the header's fields, in the header's order
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dopf.h")).read(), flags=re.S)
+    for cname, mirror in (("dopf_timing", _capi.DopfTiming), ("dopf_central_result", _capi.DopfCentralResult)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if decl:
+                ctype, names = decl.split(" ", 1)
+                fields += [(n.strip(), {"double": ctypes.c_double, "int32_t": ctypes.c_int32}[ctype]) for n in names.split(",")]
+        assert [(n, t) for n, t in mirror._fields_] == fields, cname
 
 
 def test_no_cpu_fallback_in_product_package():
