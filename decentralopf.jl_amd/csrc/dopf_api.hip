@@ -748,6 +748,7 @@ int dopf_local_update(dopf_ctx *c)
 {
     if (!c) return DOPF_E_INVALID;
     DeviceGuard guard(c->device);
+    c->quiet = false;                      // (iterations driven from outside: the next dopf_iterate looks at the flags before it trusts them)
     enqueue_local(c, false);
     HIPCHK(c, hipGetLastError());
     return DOPF_OK;
@@ -757,6 +758,7 @@ int dopf_apply_consensus(dopf_ctx *c)
 {
     if (!c) return DOPF_E_INVALID;
     DeviceGuard guard(c->device);
+    c->quiet = false;
     enqueue_apply(c, false);
     HIPCHK(c, hipGetLastError());
     return DOPF_OK;
