@@ -77,6 +77,8 @@ SYNTH = [
     ("net-118x186-config3-shape", dict(n_gen=900, n_sto=90, T=12, N=118, L=186, seed=19, fmax_factor=0.7, fmax_min=20), dict(gamma=0.002), 1, 4, 1e-7),
     ("net-4x5-T73-generator-blocks-of-three-column-passes", dict(n_gen=60, n_sto=8, T=73, N=4, L=5, seed=47, fmax_factor=0.7, fmax_min=5), dict(gamma=0.02), 1, 8, 1e-8),
     ("net-4x5-T1", dict(n_gen=30, n_sto=6, T=1, N=4, L=5, seed=48, fmax_factor=0.7, fmax_min=5), dict(gamma=0.03), 1, 12, 1e-8),
+    ("net-4x5-T250-scan-kernel-only", dict(n_gen=20, n_sto=6, T=250, N=4, L=5, seed=50, fmax_factor=0.7, fmax_min=5), dict(gamma=0.03), 1, 4, 1e-8),
+    ("net-40x60-T250-wide-and-long", dict(n_gen=60, n_sto=8, T=250, N=40, L=60, seed=51, fmax_factor=0.8, fmax_min=5), dict(gamma=0.02), 1, 3, 1e-7),
     ("net-4x5-T2", dict(n_gen=30, n_sto=6, T=2, N=4, L=5, seed=49, fmax_factor=0.7, fmax_min=5), dict(gamma=0.03), 1, 12, 1e-8),
     ("net-30x45-T96-three-launch-chain (k_net_agents, k_slack, k_dual_price_t1024 with the slack sums)",
      dict(n_gen=120, n_sto=24, T=96, N=30, L=45, seed=41, fmax_factor=0.7, fmax_min=10), dict(gamma=0.01), 1, 5, 1e-7),
