@@ -410,7 +410,9 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         // (on short blocks the skip test costs more than the rows it saves: measured on config1/config2)
         v.genSkip = (v.genTT2 > 0 && chunk >= 8 * R && !(q->flags & DOPF_F_NO_ROW_SKIP)) ? 1 : 0;
         const int NG = S > 0 ? 256 / lc.stoLPS : 1;
-        int schunk = std::max(NG, (S + 2047) / 2048);
+        int sto_target = 2048;
+        if (const char *e = getenv("DOPF_STO_TARGET_ITEMS")) sto_target = std::max(1, atoi(e));     // (experiments)
+        int schunk = std::max(NG, (S + sto_target - 1) / sto_target);
         schunk = (schunk + NG - 1) / NG * NG;
         make_items(snode, N, schunk, sitems, nsb, nsib);
         v.stoChunk = (N == 1 && !getenv("DOPF_NO_STO_CHUNK")) ? schunk : 0;
