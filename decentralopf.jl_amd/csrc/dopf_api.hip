@@ -328,6 +328,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     const int A = q->n_agents_global > 0 ? q->n_agents_global : G + S;
     v.invA = A > 0 ? 1.0 / (double)A : 0.0;
     v.use_warm = (S > 0 && lc.stoNCH <= 3 && !(q->flags & DOPF_F_NO_WARM_START)) ? 1 : 0;
+    v.stoLean = (q->flags & DOPF_F_STO_GENERAL) ? 0 : 1;        // (the launch picks it where it applies: no lines, T == LPS * NCH, LPS <= 32)
     v.genTT = std::min(T, 512);
     v.genR = 512 / v.genTT;
     v.genTT2 = (L == 0 && T % 2 == 0 && T / 2 <= 512) ? T / 2 : 0;

@@ -90,6 +90,7 @@ struct DevView {
     int fuseNet;                    // networks: generators + storages in one launch (k_net_agents), single-GPU chain
     int fuseAgents;                 // copper plate, even T: generators + storages in one launch (k_agents, 256-thread blocks)
     int use_warm;                   // storage warm-start kernel runs first; the scan kernel serves its failures
+    int stoLean;                    // copper plates whose horizon fills the lane groups: the lean active-set body (sto_lean.h)
     int max_iters;
     int keepDeltas;                 // DOPF_F_KEEP_DELTAS: dltG / dltS are written for every timestep (diagnostic getters)
     int rootCap;                    // iteration cap of the scan kernel's root search (80; 2 with DOPF_F_DEBUG_ROOT_CAP)

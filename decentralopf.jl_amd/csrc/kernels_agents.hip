@@ -2110,6 +2110,10 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
     return blockFail;
 }
 
+}  // namespace dopf
+#include "sto_lean.h"
+namespace dopf {
+
 // The scan body as a function of its own (networks): called by k_sto_warm for the rare item the active-set body leaves
 // something of. Inlined, its registers crowd the active-set body (255 VGPRs and spills, 40 % slower, measured); as a
 // separate launch it cost 4 us + a launch gap per iteration for finding nothing to do.
@@ -2226,6 +2230,43 @@ __global__ __launch_bounds__(256, 3) void k_agents(DevView v)
 #endif
 }
 
+// The same two launches with the lean copper-plate storage body (sto_lean.h): horizon == LPS * NCH, at most 32 lanes per storage.
+template <int LPS, int NCH, bool TAIL>
+__global__ __launch_bounds__(256, 3) void k_sto_l(DevView v)
+{
+    if (TAIL && (int)blockIdx.x == v.nStoItems) { tail_block(v.self); return; }
+    const int left = sto_lean_body<LPS, NCH, TAIL>(v, blockIdx.x, v.st->halt);
+    if (left < 0) return;
+    sto_cold_body<LPS, NCH, false, TAIL, true>(v, blockIdx.x, left);
+}
+
+template <int LPS, int NCH, bool SKIP, bool TAIL>
+__global__ __launch_bounds__(256, 3) void k_agents_l(DevView v)
+{
+    const int nS = v.nStoItems;
+#if defined(DOPF_STATS) || defined(DOPF_BLOCK_STAMPS)
+    if (threadIdx.x == 0 && blockIdx.x < 8192 * 4) g_timeline[32768 + 2 * blockIdx.x] = wall_clock64();
+#endif
+    if (TAIL && blockIdx.x == gridDim.x - 1) {
+        tail_block(v.self);
+    } else if (!SKIP && (int)blockIdx.x >= nS) {
+        if (v.genBlocks > 0) gen_pair_stream<256, TAIL>(v, blockIdx.x - nS, v.genBlocks);
+        else gen_pair_body<256, TAIL, true>(v, blockIdx.x - nS);
+    } else {
+        if ((int)blockIdx.x < nS) {
+            const int left = sto_lean_body<LPS, NCH, TAIL>(v, blockIdx.x, v.st->halt);
+            if (left >= 0) sto_cold_body<LPS, NCH, false, TAIL, true>(v, blockIdx.x, left);
+        } else {
+            if (v.st->halt) return;
+            gen_pair_skip_body<256, TAIL>(v, blockIdx.x - nS);
+        }
+    }
+#if defined(DOPF_STATS) || defined(DOPF_BLOCK_STAMPS)
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 8192 * 4) g_timeline[32768 + 2 * blockIdx.x + 1] = wall_clock64();
+#endif
+}
+
 int debug_timeline(unsigned long long *out, int n)
 {
 #if defined(DOPF_STATS) || defined(DOPF_BLOCK_STAMPS)
@@ -2258,6 +2299,13 @@ static void launch_sto_t(const DevView &v, hipStream_t s)
 #else
         const bool full = v.T == LPS * NC;
 #endif
+        if constexpr (LPS <= 32) {
+            if (full && v.stoLean) {
+                if (v.tail) hipLaunchKernelGGL((k_sto_l<LPS, NC, true>), dim3(v.nStoItems + 1), dim3(256), 0, s, v);
+                else hipLaunchKernelGGL((k_sto_l<LPS, NC, false>), dim3(v.nStoItems), dim3(256), 0, s, v);
+                return;
+            }
+        }
         if (v.tail) {
             if (full) hipLaunchKernelGGL((k_sto<LPS, NC, false, true, true>), dim3(v.nStoItems + 1), dim3(256), 0, s, v);
             else hipLaunchKernelGGL((k_sto<LPS, NC, false, true, false>), dim3(v.nStoItems + 1), dim3(256), 0, s, v);
@@ -2283,6 +2331,15 @@ static void launch_agents_t(const DevView &v, hipStream_t s)
 #else
     const bool fullA = v.T == LPS * NCH;
 #endif
+    if constexpr (LPS <= 32) {
+        if (fullA && v.stoLean) {
+#define DOPF_AGL(SKIP_, TAIL_) hipLaunchKernelGGL((k_agents_l<LPS, NCH, SKIP_, TAIL_>), grid, dim3(256), 0, s, v);
+            if (v.tail) { if (v.genSkip) DOPF_AGL(true, true) else DOPF_AGL(false, true) }
+            else { if (v.genSkip) DOPF_AGL(true, false) else DOPF_AGL(false, false) }
+#undef DOPF_AGL
+            return;
+        }
+    }
 #define DOPF_AG(SKIP_, TAIL_) { if (fullA) hipLaunchKernelGGL((k_agents<LPS, NCH, SKIP_, TAIL_, true>), grid, dim3(256), 0, s, v); \
                               else hipLaunchKernelGGL((k_agents<LPS, NCH, SKIP_, TAIL_, false>), grid, dim3(256), 0, s, v); }
     if (v.tail) {

@@ -121,6 +121,8 @@ typedef struct dopf_params {
 #define DOPF_F_TIME_CALLS  8192  /* measurement: dopf_iterate brackets its launches with a HIP event pair on the context's stream;
                                    dopf_last_call_ms returns the device-side span of the last call's iterations (no host launch
                                    latency in front, no status read-back behind) */
+#define DOPF_F_STO_GENERAL 16384 /* storages: the general active-set body (kernels_agents.hip: sto_warm_body) also where the lean
+                                  * copper-plate body (sto_lean.h) applies — the two are compared by the tests */
 #define DOPF_F_DEBUG_LEAVE  2048  /* tests: the active-set storage body declares every third storage uncertified, so that the
                                    hand-over to the scan body is exercised in every kernel variant                        */
 #define DOPF_F_DEBUG_ROOT_CAP 128 /* tests: the scan kernel's root search gives up after 2 iterations instead of
