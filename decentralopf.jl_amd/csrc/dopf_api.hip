@@ -327,6 +327,10 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     v.debugLeave = (q->flags & DOPF_F_DEBUG_LEAVE) ? 1 : 0;
     const int A = q->n_agents_global > 0 ? q->n_agents_global : G + S;
     v.invA = A > 0 ? 1.0 / (double)A : 0.0;
+    {
+        const double a0 = v.w_prox + v.gamma;
+        v.cp_ia = 1.0 / a0; v.cp_idet = 1.0 / (a0 * a0 - v.gamma * v.gamma); v.cp_s2 = 2.0 / (a0 + v.gamma);
+    }
     v.use_warm = (S > 0 && lc.stoNCH <= 3 && !(q->flags & DOPF_F_NO_WARM_START)) ? 1 : 0;
     v.stoLean = (q->flags & DOPF_F_STO_GENERAL) ? 0 : 1;        // (the launch picks it where it applies: no lines, T == LPS * NCH, LPS <= 32)
     v.genTT = std::min(T, 512);

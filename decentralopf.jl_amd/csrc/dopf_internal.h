@@ -95,6 +95,7 @@ struct DevView {
     int keepDeltas;                 // DOPF_F_KEEP_DELTAS: dltG / dltS are written for every timestep (diagnostic getters)
     int rootCap;                    // iteration cap of the scan kernel's root search (80; 2 with DOPF_F_DEBUG_ROOT_CAP)
     double gamma, w_flow, w_prox, eps, mask_thr, invA;
+    double cp_ia, cp_idet, cp_s2;   // copper-plate box2 constants with a = w_prox + gamma, b = gamma: 1/a, 1/(a^2 - b^2), 2/(a + b) (host: no divisions per block)
     // problem (read-only)
     const double *demand, *ptdf, *fmax;
     const double *ptdfT;                            // [n + N*l]: the transpose, for the price kernel's node-major threads

@@ -50,6 +50,28 @@ __device__ __forceinline__ double lz_dpp_id(double x, double idv)
     return __hiloint2double(hi, lo);
 }
 
+// v_min_f64 / v_max_f64 as they are: the compiler puts a canonicalising `v_max_f64 x, x` in front of every fmin / fmax whose
+// operand was assembled from the integer halves a DPP move delivers (a third of the certificate's arithmetic). No NaN
+// enters these chains (finite values and +-inf, combined by min / max only).
+__device__ __forceinline__ double lz_min(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double lz_minabs(double a, double b)          // min(|a|, |b|)
+{
+    double r;
+    asm("v_min_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double lz_max(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int LPS>
 __device__ __forceinline__ double lz_prev(double x)          // previous lane (the group's first lane: unspecified, finite)
 {
@@ -98,8 +120,8 @@ __device__ __forceinline__ void lz_chain_scan(double &M, double &G, int lane)
     {                                                                                \
         const double pM = lz_dpp_id<CTRL, (LPS <= 16)>(M, LOWER ? -INFINITY : INFINITY);   \
         const double pG = lz_dpp_id<CTRL, (LPS <= 16)>(G, LOWER ? INFINITY : -INFINITY);   \
-        if (LOWER) { M = fmax(M, fmin(G, pM)); G = fmin(G, pG); }                     \
-        else { M = fmin(M, fmax(G, pM)); G = fmax(G, pG); }                           \
+        if (LOWER) { M = lz_max(M, lz_min(G, pM)); G = lz_min(G, pG); }               \
+        else { M = lz_min(M, lz_max(G, pM)); G = lz_max(G, pG); }                     \
     }
     // (groups of at most one row: a lane whose source is outside the row has taken in the group's blocked last lane by then and
     // ignores the zeros it reads; groups of two rows: the last lanes of the first row read the identity instead)
@@ -111,8 +133,8 @@ __device__ __forceinline__ void lz_chain_scan(double &M, double &G, int lane)
     if (LPS >= 32) {                                         // rows 0, 2 take the whole of the next row (its first lane)
         const double pM = __shfl(M, (lane | 15) + 1), pG = __shfl(G, (lane | 15) + 1);
         if ((lane & 16) == 0) {
-            if (LOWER) { M = fmax(M, fmin(G, pM)); G = fmin(G, pG); }
-            else { M = fmin(M, fmax(G, pM)); G = fmax(G, pG); }
+            if (LOWER) { M = lz_max(M, lz_min(G, pM)); G = lz_min(G, pG); }
+            else { M = lz_min(M, lz_max(G, pM)); G = lz_max(G, pG); }
         }
     }
 }
@@ -126,7 +148,7 @@ __device__ __forceinline__ void lz_seg_maxmin(double K, double &a, double &b)
     {                                                                                \
         const double pa = lz_dpp_id<CTRL, (LPS <= 16)>(a, -INFINITY), pb = lz_dpp_id<CTRL, (LPS <= 16)>(b, INFINITY); \
         const double pK = lz_dpp_id<CTRL, (LPS <= 16)>(K, INFINITY);                   \
-        a = fmax(a, fmin(K, pa)); b = fmin(b, fmax(-K, pb)); K = fmin(K, pK);         \
+        a = lz_max(a, lz_min(K, pa)); b = lz_min(b, lz_max(-K, pb)); K = lz_min(K, pK); \
     }
     DOPF_LZ_STEP(0x111)
     if (LPS >= 4) DOPF_LZ_STEP(0x112)
@@ -145,7 +167,7 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
     constexpr int MAXR = 16;                 // contact-set rounds per storage
     constexpr int MAXN = 40;                 // Newton iterations per round
     constexpr int BIG = 0x3fffffff;
-    __shared__ double red[NG * T];           // nuL: price of the segment that ends here (also the final reduction's buffer)
+    __shared__ double red[NG * T];           // nuL: price of the segment that ends here
     __shared__ double fdL[NG * T];           // flat segment: signed distance to the nearest kink ahead; release flags of the left-to-right pass
     const int tid = threadIdx.x, lane = tid & 63, li = tid & (LPS - 1), grp = tid / LPS;
     const int gbase = lane & ~(LPS - 1);
@@ -154,7 +176,7 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
     else it = v.sto_items[blk];
     const int N = v.N;
     const double w = v.w_prox, gam = v.gamma;
-    const double a0 = w + gam, ia0 = 1.0 / a0, idet0 = 1.0 / (a0 * a0 - gam * gam), s20 = 2.0 / (a0 + gam);
+    const double a0 = w + gam, ia0 = v.cp_ia, idet0 = v.cp_idet, s20 = v.cp_s2;      // (host: the same expressions)
     const int tbase = li * NCH;
     double *nuL = red + grp * T, *fd_ = fdL + grp * T;
     const bool first = li == 0, last = li == LPS - 1;
@@ -164,6 +186,15 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
     int anyFail = 0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) accQ[c] = 0.0;
+    // price + gamma * imbalance of the lane's steps: the same for every storage pass of the block. Parked in LDS (one read per
+    // step and pass) instead of registers (the kernel sits at its register limit) or two more loads per step and pass, whose
+    // addresses cost a v_readlane each once the solve has taken the scalar registers.
+    __shared__ double th0L[T];
+    if (tid < LPS) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) th0L[tbase + c] = v.price[it.node + N * (tbase + c)] + gam * v.s[tbase + c];
+    }
+    __syncthreads();
 #ifdef DOPF_STATS
     unsigned long long st_rounds = 0, st_newton = 0, st_short = 0;
 #endif
@@ -171,17 +202,26 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
     for (int rep = 0; rep < nRep; ++rep) {
         const int s = it.a0 + rep * NG + grp;
         const bool live = s < it.a1;
-        const double mc = live ? v.sto_mc[s] : 0.0, pm = live ? v.sto_pmax[s] : 0.0, em = live ? v.sto_emax[s] : 0.0;
-        const bool havenu = live && v.nu_valid[s] != 0;
+        // The arrays' addresses are read from the view's copy in device memory where they are needed (scalar loads, issued
+        // with the rows' loads) instead of being held in scalar registers across the solve: the solve keeps ~20 lane masks in
+        // scalar register pairs, and every address held beside them was a v_writelane / v_readlane pair per pass.
+#ifdef LZ_PV_LOAD
+        const DevView *pv = v.self;
+        asm volatile("" : "+s"(pv));
+#else
+        const DevView *pv = &v;
+#endif
+        const double mc = live ? pv->sto_mc[s] : 0.0, pm = live ? pv->sto_pmax[s] : 0.0, em = live ? pv->sto_emax[s] : 0.0;
+        const bool havenu = live && pv->nu_valid[s] != 0;
         double A0[NCH], B0[NCH], nuv[NCH], dq[NCH];      // rD = A0 - nu, rC = B0 + nu
         double run = 0.0;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int t = tbase + c;
             const size_t e = (size_t)s * T + (live ? t : 0);
-            const double d0 = live ? v.D[e] : 0.0, c0 = live ? v.C[e] : 0.0;
-            const double nu_st = v.nu_prev[live ? e : 0];      // (always loaded, from a valid address: sto_warm_body)
-            const double th0 = v.price[it.node + N * t] + gam * v.s[t];
+            const double d0 = live ? pv->D[e] : 0.0, c0 = live ? pv->C[e] : 0.0;
+            const double nu_st = pv->nu_prev[live ? e : 0];      // (always loaded, from a valid address: sto_warm_body)
+            const double th0 = th0L[t];
             const double theta = th0 - gam * (d0 - c0);
             dq[c] = c0 - d0;
             run += c0 - d0;
@@ -339,11 +379,11 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const double d = cand[q] - nuv[c];
-                            if (d > 0.0) du = fmin(du, d);
-                            if (d < 0.0) dn = fmin(dn, -d);
+                            if (d > 0.0) du = lz_min(du, d);
+                            if (d < 0.0) dn = lz_min(dn, -d);
                         }
                         if (keep[c] == 0.0) { ru = -INFINITY; rd = INFINITY; }
-                        ru = fmax(ru, -du); rd = fmin(rd, dn);
+                        ru = lz_max(ru, -du); rd = lz_min(rd, dn);
                         fu[c] = ru; fn[c] = rd;
                     }
                     double au = ru, ad = rd;
@@ -351,7 +391,7 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
                     const double cu = lz_prev<LPS>(au), cd = lz_prev<LPS>(ad);
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) {
-                        if (pk[c] != 0.0) { fu[c] = fmax(fu[c], cu); fn[c] = fmin(fn[c], cd); }
+                        if (pk[c] != 0.0) { fu[c] = lz_max(fu[c], cu); fn[c] = lz_min(fn[c], cd); }
                         if (en[c] && kind[c] != 0) fd_[tbase + c] = res[c] < 0.0 ? -fu[c] : -fn[c];
                     }
                 }
@@ -409,12 +449,15 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
                 double slo[NCH], shi[NCH];
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    double lo = -INFINITY, hi = INFINITY;
                     const double dd = Dv[c], cc = Cv[c];
-                    if (dd <= 0.0) lo = A0[c] + gam * cc; else if (dd >= pm) hi = A0[c] - a0 * pm + gam * cc;
-                    if (cc <= 0.0) hi = fmin(hi, -B0[c] - gam * dd); else if (cc >= pm) lo = fmax(lo, a0 * pm - gam * dd - B0[c]);
+                    // D = 0: nu >= A0 + gam C; D = pm: nu <= that - a pm; C = 0: nu <= -B0 - gam D; C = pm: nu >= that + a pm
+                    const double lD = fma(gam, cc, A0[c]), hC = -fma(gam, dd, B0[c]), apm = a0 * pm;
+                    double lo = dd <= 0.0 ? lD : -INFINITY;
+                    double hi = (dd > 0.0 && dd >= pm) ? lD - apm : INFINITY;
+                    hi = lz_min(hi, cc <= 0.0 ? hC : INFINITY);
+                    lo = lz_max(lo, (cc > 0.0 && cc >= pm) ? hC + apm : -INFINITY);
                     const double K = keep[c] != 0.0 ? INFINITY : -INFINITY;
-                    rl = fmax(lo, fmin(K, rl)); rh = fmin(hi, fmax(-K, rh));
+                    rl = lz_max(lo, lz_min(K, rl)); rh = lz_min(hi, lz_max(-K, rh));
                     slo[c] = rl; shi[c] = rh;
                 }
                 double al = rl, ah = rh;
@@ -429,7 +472,7 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
                         else if (px[c] > em + tolE) { okk = false; nkind[c] = 2; }
                     }
                     const double Kp = pk[c] != 0.0 ? INFINITY : -INFINITY;
-                    const double sl_ = fmax(slo[c], fmin(Kp, cl)), sh_ = fmin(shi[c], fmax(-Kp, ch));
+                    const double sl_ = lz_max(slo[c], lz_min(Kp, cl)), sh_ = lz_min(shi[c], lz_max(-Kp, ch));
                     const double pt = kind[c] != 0 ? nuv[c] : 0.0;
                     // flat segment (zero slope at its end = every step on a corner): the whole interval
                     const bool flat = contact && ps[c] == 0.0 && sl_ <= sh_ && nuv[c] >= sl_ - 1e-9 && nuv[c] <= sh_ + 1e-9;
@@ -448,8 +491,8 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
 #define LZ_GH(c) ((!en[c] || kind[c] == 2) ? -INFINITY : INFINITY)
 #pragma unroll
                 for (int c = NCH - 1; c >= 0; --c) {
-                    Ml = fmax(LZ_EL(c), fmin(LZ_GL(c), Ml)); Gl = fmin(LZ_GL(c), Gl);
-                    Mh = fmin(LZ_EH(c), fmax(LZ_GH(c), Mh)); Gh = fmax(LZ_GH(c), Gh);
+                    Ml = lz_max(LZ_EL(c), lz_min(LZ_GL(c), Ml)); Gl = lz_min(LZ_GL(c), Gl);
+                    Mh = lz_min(LZ_EH(c), lz_max(LZ_GH(c), Mh)); Gh = lz_max(LZ_GH(c), Gh);
                 }
                 lz_chain_scan<LPS, true>(Ml, Gl, lane);
                 lz_chain_scan<LPS, false>(Mh, Gh, lane);
@@ -458,13 +501,13 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
                 double flo = last ? 0.0 : nextMl, fhi = last ? 0.0 : nextMh;
 #pragma unroll
                 for (int c = NCH - 1; c >= 0; --c) {
-                    flo = fmax(LZ_EL(c), fmin(LZ_GL(c), flo));
-                    fhi = fmin(LZ_EH(c), fmax(LZ_GH(c), fhi));
+                    flo = lz_max(LZ_EL(c), lz_min(LZ_GL(c), flo));
+                    fhi = lz_min(LZ_EH(c), lz_max(LZ_GH(c), fhi));
                     nuc[c] = nuv[c];
                     if (en[c] && kind[c] != 0) {
-                        const double tn = 1e-10 * (1.0 + fmin(fabs(flo), fabs(fhi)));
+                        const double tn = 1e-10 * (1.0 + lz_minabs(flo, fhi));
                         if (flo > fhi + tn) { okk = false; nkind[c] = 0; }      // wrong sign: release the contact
-                        nuc[c] = clampd(nuv[c], flo, fmax(flo, fhi));
+                        nuc[c] = lz_min(lz_max(nuv[c], flo), lz_max(flo, fhi));
                     }
                 }
 #undef LZ_EL
@@ -533,12 +576,18 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
             if (!gdone && cert) {
                 int s_ = s;
                 asm volatile("" : "+v"(s_));
+#ifdef LZ_PV_STORE
+                const DevView *pw = v.self;
+                asm volatile("" : "+s"(pw));
+#else
+                const DevView *pw = &v;
+#endif
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const size_t e = (size_t)s_ * T + tbase + c;
-                    v.D[e] = Dv[c];
-                    v.C[e] = Cv[c];
-                    v.nu_prev[e] = nuc[c] + 0.5 * (B0[c] - A0[c] - w * dq[c]);      // nu + theta (theta back from the step's offsets)
+                    pw->D[e] = Dv[c];
+                    pw->C[e] = Cv[c];
+                    pw->nu_prev[e] = nuc[c] + 0.5 * (B0[c] - A0[c] - w * dq[c]);      // nu + theta (theta back from the step's offsets)
                     accQ[c] += Dv[c] - Cv[c];
                     accCost += mc * (Dv[c] + Cv[c]);
                 }
@@ -555,7 +604,15 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
 #undef LZ_TGT
         }
 
-        if (live && first) { v.sto_fail[s] = good ? 0 : 1; if (good) v.nu_valid[s] = 1; }
+        {
+#ifdef LZ_PV_STORE
+            const DevView *pe = v.self;
+            asm volatile("" : "+s"(pe));
+#else
+            const DevView *pe = &v;
+#endif
+            if (live && first) { pe->sto_fail[s] = good ? 0 : 1; if (good) pe->nu_valid[s] = 1; }
+        }
         if (live && !good && first) anyFail += 1;
         __builtin_amdgcn_wave_barrier();
     }
@@ -567,9 +624,18 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
     if (st_newton) atomicMax(&v.st->dbg_reason[3], st_newton);
 #endif
 
-    // the block's sums with ONE barrier (sto_warm_body's epilogue)
+    // The block's sums with ONE barrier.
+    // The lane groups of a wave meet in a butterfly (lanes with the same timesteps sit LPS
+    // apart: a fixed order), the four waves through LDS in wave order. (sto_warm_body: one lane group walks all NG rows in LDS.)
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) red[(grp * LPS + li) * NCH + c] = accQ[c];
+    for (int c = 0; c < NCH; ++c) {
+        double x = accQ[c];
+        if (LPS <= 8) x += lz_dpp<0x128>(x);                 // row_ror:8 (the lane 8 further on, modulo the row)
+        if (LPS <= 16) x += __shfl_xor(x, 16);
+        x += __shfl_xor(x, 32);
+        accQ[c] = x;
+    }
+    __shared__ double wsumS[4][T];
     __shared__ double wcostS[4];
     __shared__ int wfailS[4];
     {
@@ -577,27 +643,37 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
         int fw = anyFail;
         for (int d = 32; d > 0; d >>= 1) { cw += __shfl_xor(cw, d); fw += __shfl_xor(fw, d); }
         if (lane == 0) { wcostS[tid >> 6] = cw; wfailS[tid >> 6] = fw; }
+        if (lane < LPS) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) wsumS[tid >> 6][tbase + c] = accQ[c];
+        }
     }
+#ifndef LZ_NO_PV_FINAL
+    const DevView *pf = v.self;                                  // (addresses from the view's copy in device memory: see the passes)
+    asm volatile("" : "+s"(pf));
+#else
+    const DevView *pf = &v;
+#endif
     TailView tv{};
     int tpar = 0;
-    if (TAIL) { tv = *v.tail; tpar = v.st->tail_par; }          // (uniform scalar loads, in flight across the barrier)
+    if (TAIL) { tv = *pf->tailDev; tpar = pf->st->tail_par; }   // (TAIL: this launch adds into the accumulators; uniform scalar loads,
+                                                                // in flight across the barrier. The per-launch fields of the view live in the kernel arguments only.)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const int blockFail = wfailS[0] + wfailS[1] + wfailS[2] + wfailS[3];
-    if (grp == 0) {
+    if (tid < LPS) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int t = tbase + c;
-            double sum = 0.0;
-            for (int g2 = 0; g2 < NG; ++g2) sum += red[(g2 * LPS + li) * NCH + c];
+            const double sum = ((wsumS[0][t] + wsumS[1][t]) + wsumS[2][t]) + wsumS[3][t];
             if (TAIL && blockFail == 0) acc_add(tv, tpar, t, sum, tv.scaleInj);
-            else v.part_sinj_w[(size_t)blk * T + t] = sum;
+            else pf->part_sinj_w[(size_t)blk * T + t] = sum;
         }
     }
     if (tid == 0) {
         const double cw = ((wcostS[0] + wcostS[1]) + wcostS[2]) + wcostS[3];
         if (TAIL && blockFail == 0) acc_add(tv, tpar, T, cw, tv.scaleCost);
-        else v.part_scost_w[blk] = cw;
-        v.item_fail[blk] = blockFail;
+        else pf->part_scost_w[blk] = cw;
+        pf->item_fail[blk] = blockFail;
     }
     if (blockFail != 0) __syncthreads();
     return blockFail;

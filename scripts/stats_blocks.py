@@ -11,7 +11,7 @@ import bench
 wl = sys.argv[1] if len(sys.argv) > 1 else "config2"         # config2 (k_agents) or a network workload (k_net_agents)
 pp = bench.make_problem(synth, wl); A = pp.G + pp.S
 _capi._pin_hip_runtime()
-e = _capi.Engine(api, params=_capi.default_params(gamma=1.0 / A, w_flow=10.0 if pp.L == 0 else 0.3 / A, eps=0.0, flags=_capi.F_NO_GRAPH), **pp.engine_kwargs())
+e = _capi.Engine(api, params=_capi.default_params(gamma=1.0 / A, w_flow=10.0 if pp.L == 0 else 0.3 / A, eps=0.0, flags=_capi.F_NO_GRAPH | (int(sys.argv[3]) if len(sys.argv) > 3 else 0)), **pp.engine_kwargs())
 e.iterate(300 if pp.L else 150)
 n = 8192 * 16
 buf = (C.c_uint64 * n)()
