@@ -133,9 +133,11 @@ def cpu_baseline(pp, gamma, w_flow, synth, budget_s=14.0):
     return out
 
 
-def self_launch(args, argv):
+def self_launch(args, argv, child_cmd=None, min_budget=20.0):
     """--gpus N without a launcher: start the N ranks as children (this process never touches the GPU), relay
-    rank 0's JSON line. A run that hangs is killed at the deadline and retried on the next communication mode."""
+    rank 0's JSON line. A run that hangs is killed at the deadline and retried on the next communication mode.
+    child_cmd(mode, port, rest) -> argv of the child (tests substitute stub children; default: torch.distributed.run on this
+    file); min_budget: floor of one attempt's share of --launch-timeout."""
     import socket
     # auto: the ranks try the library communicator and fall back to torch in place when it raises; a hang is this
     # watchdog's business, and the second attempt then goes straight to torch
@@ -156,15 +158,18 @@ def self_launch(args, argv):
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + \
-              rest + [f"--comm={mode}"]
+        if child_cmd is not None:
+            cmd = child_cmd(mode, port, rest)
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + \
+                  rest + [f"--comm={mode}"]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                    DOPF_BENCH_LOST_ATTEMPTS=json.dumps(lost))
         # the whole run has ONE budget (--launch-timeout): the first attempt may use 60 % of what is left, so that the
         # fallback attempt (torch only) still fits under the caller's own limit
         left = t_end - time.time()
-        budget = max(20.0, left * (0.6 if mode != modes[-1] else 1.0))
+        budget = max(min_budget, left * (0.6 if mode != modes[-1] else 1.0))
         p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=sys.stderr, env=env, start_new_session=True)
         try:
             out, _ = p.communicate(timeout=budget)

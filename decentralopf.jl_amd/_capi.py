@@ -68,6 +68,12 @@ F_KEEP_DELTAS = 256
 F_COMM_GRAPH = 512
 F_COMM_P2P = 1024
 F_DEBUG_LEAVE = 2048
+F_STO_GENERAL = 16384
+F_NO_QUIET = 32768
+F_XCHG_OWNER = 65536
+F_XCHG_ALLGATHER = 131072
+F_NO_TAIL_XCHG = 262144
+F_NET_SMALL_ITEMS = 524288
 COMM_ID_BYTES = 128
 XCHG_HANDLE_BYTES = 64
 
@@ -138,6 +144,7 @@ class CApi:
             self._sig("get_agent_slacks", C.c_int, [ctxp, C.c_int32, c_double_p, c_double_p])
             self._sig("get_agent_penalty", C.c_int, [ctxp, C.c_int32, c_double_p, c_double_p])
             self._sig("get_residual_vectors", C.c_int, [ctxp, c_double_p, c_double_p, c_double_p])
+            self._sig("get_penalty_sums", C.c_int, [ctxp, c_double_p])
             self._sig("central_solve", C.c_int, [C.POINTER(DopfProblem), C.POINTER(DopfParams), C.c_double, C.c_int32,
                                                  C.POINTER(DopfCentralResult)] + [c_double_p] * 9)
             self._sig("get_node_results", C.c_int, [ctxp, c_double_p, c_double_p, c_double_p])
@@ -420,6 +427,13 @@ class Engine:
         pen = np.zeros(3 * self.T)
         d = None if delta is None else _f64(delta, self.T)
         self._chk(self.api.get_agent_penalty(self._ctx, int(agent), _dp(d), _dp(pen)))
+        return pen[:self.T].copy(), pen[self.T:2 * self.T].copy(), pen[2 * self.T:].copy()
+
+    def get_penalty_sums(self):
+        """Result.penalty_term (results.jl:66-70): the three penalty vectors summed over all agents, (T) each. Networks
+        with F_KEEP_DELTAS (the device must hold the injection changes of the last x-update)."""
+        pen = np.zeros(3 * self.T)
+        self._chk(self.api.get_penalty_sums(self._ctx, _dp(pen)))
         return pen[:self.T].copy(), pen[self.T:2 * self.T].copy(), pen[2 * self.T:].copy()
 
     def get_nodal_price(self, which: int = 0):

@@ -79,6 +79,7 @@ class Result:
     injection: np.ndarray
     line_utilization: np.ndarray
     node_to_result: Dict[int, ResultNode] = field(default_factory=dict)
+    penalty_term: Optional[PenaltyTerm] = None      # results.jl:66-70 (sum over the units); filled with record_slacks=True
 
     def of(self, unit):
         return self.unit_to_result[id(unit)]
@@ -165,8 +166,17 @@ class ADMM:
             np.add.at(nd, np.asarray(self.packed.sto_node, dtype=np.int64), D)
             np.add.at(nc, np.asarray(self.packed.sto_node, dtype=np.int64), C)
         n2r = {id(n): ResultNode(n, ng[i].copy(), nd[i].copy(), nc[i].copy()) for i, n in enumerate(self.nodes)}
+        pen = None
+        if self.record_slacks:
+            # Result.penalty_term = sum_up over the units (results.jl:66-70, helpers/penalty_terms.jl:1-6): one pass on the device
+            # where it holds the injection changes (networks), else the sum of the per-unit terms fetched above
+            if self.packed.L > 0 and hasattr(self.engine.api, "get_penalty_sums"):
+                pen = PenaltyTerm(*self.engine.get_penalty_sums())
+            else:
+                terms = [r.penalty_term for r in u2r.values()]
+                pen = PenaltyTerm(*(sum(getattr(t_, f) for t_ in terms) for f in ("energy_balance", "upper_flow", "lower_flow")))
         return Result(u2r, P.sum(axis=0) if P.size else np.zeros(T), D.sum(axis=0) if D.size else np.zeros(T),
-                      C.sum(axis=0) if C.size else np.zeros(T), aU, aK, cost, inj, flow, n2r)
+                      C.sum(axis=0) if C.size else np.zeros(T), aU, aK, cost, inj, flow, n2r, pen)
 
     def _after(self, done: int):
         lam_res, mu_res, rho_res, it = self.engine.get_residuals()

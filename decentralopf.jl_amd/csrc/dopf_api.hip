@@ -347,12 +347,12 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         if (sto_blocks > 3 * 256 || (long long)G * T > (8ll << 20)) v.fuseAgents = 0;
     }
     v.genR2 = v.genTT2 ? (v.fuseAgents ? 256 : 512) / v.genTT2 : 0;
-    v.coldInWarm = (L > 0 && v.use_warm && !getenv("DOPF_SPLIT_COLD")) ? 1 : 0;
+    v.coldInWarm = (L > 0 && v.use_warm && !exp_env("DOPF_SPLIT_COLD")) ? 1 : 0;
     // networks: generators and storages in one launch (k_net_agents) unless the storages run on a stream of their own
     v.genTT256 = std::max(1, std::min((std::min(T, 512) + 1) / 2, 256 / v.genR));
     v.fuseNet = (L > 0 && G > 0 && S > 0 && v.coldInWarm && !(c->q.flags & (DOPF_F_NO_FUSE | DOPF_F_OVERLAP_AGENTS)) &&
                  v.genR * v.genTT256 <= 256 &&          // (T = 1: the 512-thread tiling has more agent lanes than such a block has threads)
-                 !getenv("DOPF_NO_NET_FUSE")) ? 1 : 0;
+                 !exp_env("DOPF_NO_NET_FUSE")) ? 1 : 0;
 
     // sort agents by node (stable), remember the permutation
     c->gen_perm.resize(G);
@@ -387,7 +387,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         const bool chain = v.genTT2 > 0 && (S == 0 || v.use_warm) && G + S > 0;       // pair kernels / k_agents / k_sto
         tail_ok = (N == 1 && L == 0 && chain && ki >= 8 && kc >= 0 &&
                     !(q->flags & (DOPF_F_NO_TAIL_FUSE | DOPF_F_OVERLAP_AGENTS)) &&       // (two streams: the storage launch does not follow the generators')
-                    !getenv("DOPF_NO_TAIL_FUSE")) ? 1 : 0;
+                    !exp_env("DOPF_NO_TAIL_FUSE")) ? 1 : 0;
         tvh.accStride = (T + 1 + 15) / 16 * 16;                   // replicas on 128-byte lines of their own
         tvh.scaleInj = std::ldexp(1.0, std::max(0, std::min(ki, 60))); tvh.invInj = 1.0 / tvh.scaleInj;
         tvh.scaleCost = std::ldexp(1.0, std::max(0, std::min(kc, 60))); tvh.invCost = 1.0 / tvh.scaleCost;
@@ -402,10 +402,10 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         // (with lines ~1024 blocks: the 118-node share 93.8 -> 87.3 us per iteration, config3 at full size 204 -> 203)
         // (networks, one launch for all agents: the generator blocks pass through the ~230 wave slots the storage blocks leave
         // free at that kernel's register count — ~512 larger ones: the 118-node share 51.6 -> 49.5 us per iteration)
-        int target_items = v.fuseAgents ? 1536 : (L > 0 ? (v.fuseNet ? 512 : 1024) : 2048);
-        if (const char *e = getenv("DOPF_GEN_TARGET_ITEMS")) target_items = std::max(1, atoi(e));     // (experiments)
+        int target_items = v.fuseAgents ? 1536 : (L > 0 ? ((v.fuseNet && !(q->flags & DOPF_F_NET_SMALL_ITEMS)) ? 512 : 1024) : 2048);
+        if (const char *e = exp_env("DOPF_GEN_TARGET_ITEMS")) target_items = std::max(1, atoi(e));     // (experiments)
         // streaming generator blocks (fused launch, one node): an item is ONE batch of loads, <= kGenStreamRows rows per lane
-        const bool stream = v.fuseAgents && N == 1 && !getenv("DOPF_NO_GEN_STREAM");
+        const bool stream = v.fuseAgents && N == 1 && !exp_env("DOPF_NO_GEN_STREAM");
         if (stream) target_items = std::max(target_items, (G + kGenStreamRows * R - 1) / (kGenStreamRows * R));
         int chunk = std::max(R, (G + target_items - 1) / target_items);
         chunk = (chunk + R - 1) / R * R;
@@ -416,22 +416,22 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         v.genSkip = (v.genTT2 > 0 && chunk >= 8 * R && !(q->flags & DOPF_F_NO_ROW_SKIP)) ? 1 : 0;
         const int NG = S > 0 ? 256 / lc.stoLPS : 1;
         int sto_target = 2048;
-        if (const char *e = getenv("DOPF_STO_TARGET_ITEMS")) sto_target = std::max(1, atoi(e));     // (experiments)
+        if (const char *e = exp_env("DOPF_STO_TARGET_ITEMS")) sto_target = std::max(1, atoi(e));     // (experiments)
         int schunk = std::max(NG, (S + sto_target - 1) / sto_target);
         schunk = (schunk + NG - 1) / NG * NG;
         make_items(snode, N, schunk, sitems, nsb, nsib);
-        v.stoChunk = (N == 1 && !getenv("DOPF_NO_STO_CHUNK")) ? schunk : 0;
+        v.stoChunk = (N == 1 && !exp_env("DOPF_NO_STO_CHUNK")) ? schunk : 0;
     }
     v.maxNodeAgents = 0;
     for (int n = 0; n < N; ++n) v.maxNodeAgents = std::max(v.maxNodeAgents, (ngb[n + 1] - ngb[n]) + (nsb[n + 1] - nsb[n]));
     v.nGenItems = (int)gitems.size();
     v.nStoItems = (int)sitems.size();
     v.genBlocks = 0;
-    if (v.fuseAgents && v.genChunk > 0 && !v.genSkip && v.genChunk <= kGenStreamRows * v.genR2 && !getenv("DOPF_NO_GEN_STREAM")) {
+    if (v.fuseAgents && v.genChunk > 0 && !v.genSkip && v.genChunk <= kGenStreamRows * v.genR2 && !exp_env("DOPF_NO_GEN_STREAM")) {
         // as many generator blocks as find a wave slot next to the storage blocks (3 blocks of 256 per CU at the fused
         // kernel's register count): all resident from the start; at least a quarter of the chip
         int nb = 3 * 256 - v.nStoItems - (tail_ok ? 1 : 0);        // (tail in the launch: one slot for the tail block)
-        if (const char *e = getenv("DOPF_GEN_BLOCKS")) nb = atoi(e);          // (experiments)
+        if (const char *e = exp_env("DOPF_GEN_BLOCKS")) nb = atoi(e);          // (experiments)
         v.genBlocks = std::min(v.nGenItems, std::max(nb, 192));
     }
     v.genRows = v.genBlocks;
@@ -521,25 +521,25 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         HIPTRY(hipMemcpy(tvd, &tvh, sizeof tvh, hipMemcpyHostToDevice));
         v.tailDev = tvd;
     }
-    v.splitDual = getenv("DOPF_SPLIT_DUAL") ? 1 : 0;
+    v.splitDual = exp_env("DOPF_SPLIT_DUAL") ? 1 : 0;
     {
         // networks whose dual step is the one-launch kernel (k_dual_price_t1024: <= 256 lines and nodes, consensus state beyond the
         // one-block kernel): it builds the tables too, with as many waves as find LDS scratch (<= 8) next to its own ~30 KB
         const size_t n1 = std::max(NT, LT);
         const size_t per_wave = (4 * (size_t)v.M2 + 1) * sizeof(double), own = 25 * 1024 + (4 * (size_t)N + 3 * (size_t)L) * sizeof(double);
         int tw = 0;
-        if (L > 0 && L <= 256 && N <= 256 && n1 > kSmallConsensus && !v.splitDual && !getenv("DOPF_TABLES_LAUNCH"))
+        if (L > 0 && L <= 256 && N <= 256 && n1 > kSmallConsensus && !v.splitDual && !exp_env("DOPF_TABLES_LAUNCH"))
             tw = (int)std::min<size_t>(8, (128 * 1024 - std::min<size_t>(own, 128 * 1024)) / per_wave);
         v.tablesInDual = tw;
         // the same kernel forms the slack sums of its timestep (see DevView::slackInDual); DOPF_F_NO_TAIL_FUSE keeps the
         // k_reduce launch (the chain a sharded context runs: bitwise comparisons against it)
         v.slackDualOk = L > 0 && L <= 256 && N <= 256 && n1 > kSmallConsensus && !v.splitDual && !(q->flags & DOPF_F_NO_TAIL_FUSE) &&
-                        !getenv("DOPF_REDUCE_LAUNCH");
+                        !exp_env("DOPF_REDUCE_LAUNCH");
         // ... and, while no line is flagged, the node sums too (the quiet chain: no k_slack launch; DevView::quiet, dopf_iterate)
         // (up to 32 rows per node: one batch of the eight lanes' four loads. configs[3] at full size has 25 and is where the gain
         // ends — the node sums cost the dual kernel what k_slack and its boundary cost, 119.3 us per iteration either way)
-        c->quiet_ok = v.slackDualOk && !(q->flags & DOPF_F_KEEP_DELTAS) && (max_node_rows <= 32 || getenv("DOPF_QUIET_ANY_SIZE")) &&
-                      !getenv("DOPF_NO_QUIET");
+        c->quiet_ok = v.slackDualOk && !(q->flags & DOPF_F_KEEP_DELTAS) && (max_node_rows <= 32 || exp_env("DOPF_QUIET_ANY_SIZE")) &&
+                      !(q->flags & DOPF_F_NO_QUIET);
     }
     double *cons = nullptr;
     TRY(dev_alloc(c, &cons, NT + 2 * LT + 1));
@@ -921,21 +921,59 @@ int dopf_get_nodal_price(dopf_ctx *c, int32_t which, double *out)
     return DOPF_OK;
 }
 
+// scratch of the getters that reduce on the device: allocated once (an allocation per call would be a device-wide
+// synchronisation per Result in a record-everything loop), freed with the context's other arrays
+static int getter_scratch(dopf_ctx *c, double **out)
+{
+    if (!c->getter_scratch) {
+        int rc = dev_alloc(c, &c->getter_scratch, 3 * (size_t)c->v.N * c->v.T, false);
+        if (rc) return rc;
+    }
+    *out = c->getter_scratch;
+    return DOPF_OK;
+}
+
 int dopf_get_node_results(dopf_ctx *c, double *generation, double *discharge, double *charge)
 {
     if (!c) return DOPF_E_INVALID;
     DeviceGuard guard(c->device);
     const size_t NT = (size_t)c->v.N * c->v.T;
     double *tmp = nullptr;
-    HIPCHK(c, hipMalloc((void **)&tmp, 3 * NT * sizeof(double)));
+    int rc = getter_scratch(c, &tmp);
+    if (rc) return rc;
     launch_node_results(c->v, tmp, tmp + NT, tmp + 2 * NT, c->main);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(c->main);
+    HIPCHK(c, hipGetLastError());
     double *outs[3] = {generation, discharge, charge};
-    for (int k = 0; k < 3 && e == hipSuccess; ++k)
-        if (outs[k]) e = hipMemcpy(outs[k], tmp + k * NT, NT * sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(tmp);
-    if (e != hipSuccess) return fail(c, DOPF_E_DEVICE, "dopf_get_node_results: %s", hipGetErrorString(e));
+    for (int k = 0; k < 3; ++k)
+        if (outs[k]) HIPCHK(c, hipMemcpyAsync(outs[k], tmp + k * NT, NT * sizeof(double), hipMemcpyDeviceToHost, c->main));
+    HIPCHK(c, hipStreamSynchronize(c->main));
+    return DOPF_OK;
+}
+
+// Result.penalty_term (src/structures/results.jl:66-70): the agents' three penalty vectors summed, one device pass
+int dopf_get_penalty_sums(dopf_ctx *c, double *penalty)
+{
+    if (!c || !penalty) return DOPF_E_INVALID;
+    const DevView &v = c->v;
+    if (v.L == 0 || !v.keepDeltas)
+        return fail(c, DOPF_E_UNSUPPORTED, "the agents' injection changes are kept on the device only with lines and DOPF_F_KEEP_DELTAS "
+                                           "(otherwise: dopf_get_agent_penalty with the change passed in, agent by agent)");
+    DeviceGuard guard(c->device);
+    const size_t NT = (size_t)v.N * v.T;
+    double *tmp = nullptr;
+    int rc = getter_scratch(c, &tmp);
+    if (rc) return rc;
+    launch_penalty_sums(v, tmp, c->main);
+    HIPCHK(c, hipGetLastError());
+    std::vector<double> h(3 * NT);
+    HIPCHK(c, hipMemcpyAsync(h.data(), tmp, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->main));
+    HIPCHK(c, hipStreamSynchronize(c->main));
+    for (int k = 0; k < 3; ++k)
+        for (int t = 0; t < v.T; ++t) {
+            double sum = 0.0;
+            for (int n = 0; n < v.N; ++n) sum += h[k * NT + (size_t)n * v.T + t];       // (node order: fixed)
+            penalty[(size_t)k * v.T + t] = sum;
+        }
     return DOPF_OK;
 }
 

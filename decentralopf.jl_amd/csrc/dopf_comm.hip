@@ -303,8 +303,8 @@ void xchg_fill_view(dopf_ctx *c, dopf_comm_state *cs, int world, int rank, void 
     x.world = world; x.me = rank; x.nchunks = (int)lay.nchunks; x.n = lay.n; x.timeout_ticks = xchg_timeout_ticks();
     // more than one chunk per rank: every chunk has an owner that adds the ranks' copies and hands the sum to everybody
     // (2 n doubles in and out per rank and iteration instead of world x n)
-    x.rs = ((int)lay.nchunks > world && world > 1 && !getenv("DOPF_XCHG_ALLGATHER")) ? 1 : 0;
-    if (getenv("DOPF_XCHG_REDUCE_SCATTER")) x.rs = 1;            // (tests: the owner form on small vectors and at world 1)
+    x.rs = ((int)lay.nchunks > world && world > 1 && !(c->q.flags & DOPF_F_XCHG_ALLGATHER)) ? 1 : 0;
+    if (c->q.flags & DOPF_F_XCHG_OWNER) x.rs = 1;                // (tests: the owner form on small vectors and at world 1)
     for (int r = 0; r < world; ++r) {
         x.flags[r] = reinterpret_cast<unsigned long long *>((char *)areas[r] + lay.flags_off);
         x.sflags[r] = reinterpret_cast<unsigned long long *>((char *)areas[r] + lay.sflags_off);
@@ -317,7 +317,7 @@ void xchg_fill_view(dopf_ctx *c, dopf_comm_state *cs, int world, int rank, void 
     c->tail_xchg = false;
     // (T + 1 <= 128: all slots in one pass of the tail block's lane pairs — the flags are published once, behind the whole vector)
     if (c->v.tailDev && c->v.L == 0 && c->v.N == 1 && lay.n == (size_t)c->v.T + 1 && lay.nchunks == 1 && c->v.T + 1 <= 128 &&
-        !getenv("DOPF_NO_TAIL_XCHG")) {
+        !(c->q.flags & DOPF_F_NO_TAIL_XCHG)) {
         DeviceGuard guard(c->device);
         bool ok = cs->xdev || hipMalloc((void **)&cs->xdev, sizeof(XchgView)) == hipSuccess;
         ok = ok && hipMemcpy(cs->xdev, &x, sizeof(XchgView), hipMemcpyHostToDevice) == hipSuccess;
@@ -326,6 +326,20 @@ void xchg_fill_view(dopf_ctx *c, dopf_comm_state *cs, int world, int rank, void 
         if (!ok) (void)hipGetLastError();
         c->tail_xchg = ok;
     }
+}
+
+// A rendezvous that failed after xchg_fill_view: the context goes back to its single-GPU chain — the tail block's pointer to
+// the exchange's view is cleared on the DEVICE (the context's graphs read the TailView there), the view is marked unusable and
+// the graphs are dropped. (Without this a later dopf_iterate made the tail block exchange with peers that never joined.)
+void xchg_undo(dopf_ctx *c, dopf_comm_state *cs)
+{
+    if (c->tail_xchg && c->v.tailDev) {
+        const XchgView *none = nullptr;
+        (void)hipMemcpy((char *)const_cast<TailView *>(c->v.tailDev) + offsetof(TailView, xchg), &none, sizeof none, hipMemcpyHostToDevice);
+    }
+    c->tail_xchg = false;
+    cs->xv.world = 0;
+    drop_graphs(c);
 }
 
 }  // namespace
@@ -377,27 +391,36 @@ int dopf_xchg_init(dopf_ctx *c, int32_t world, int32_t rank, const void *handles
     // The hello word carries the rank's iteration count (+1): the exchange's sequence numbers and slot parities are
     // derived from it, so ranks that join with different counts would read each other's other slot, whose older flag
     // already passes — refused here instead.
-    if (int rcs = read_status(c)) return rcs;
+    if (int rcs = read_status(c)) { xchg_undo(c, cs); return rcs; }
     const unsigned long long one = (unsigned long long)c->host_st.iters_total + 1ull;
-    for (int r = 0; r < world; ++r)
-        HIPCHK(c, hipMemcpy((char *)areas[r] + (size_t)rank * sizeof one, &one, sizeof one, hipMemcpyHostToDevice));
+    for (int r = 0; r < world; ++r) {
+        const hipError_t e = hipMemcpy((char *)areas[r] + (size_t)rank * sizeof one, &one, sizeof one, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { xchg_undo(c, cs); return fail(c, DOPF_E_DEVICE, "peer exchange: hello to rank %d: %s", r, hipGetErrorString(e)); }
+    }
     double wait_s = 120.0;
-    if (const char *e = getenv("DOPF_XCHG_HELLO_S")) wait_s = atof(e);
+    if (const char *e = exp_env("DOPF_XCHG_HELLO_S")) wait_s = atof(e);
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         unsigned long long hello[kXchgMaxWorld];
-        HIPCHK(c, hipMemcpy(hello, cs->xbuf, sizeof hello, hipMemcpyDeviceToHost));
+        {
+            const hipError_t e = hipMemcpy(hello, cs->xbuf, sizeof hello, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { xchg_undo(c, cs); return fail(c, DOPF_E_DEVICE, "peer exchange: reading the hello words: %s", hipGetErrorString(e)); }
+        }
         int seen = 0;
         for (int r = 0; r < world; ++r) seen += hello[r] != 0ull;
         if (seen == world) {
             for (int r = 0; r < world; ++r)
-                if (hello[r] != one)
+                if (hello[r] != one) {
+                    xchg_undo(c, cs);
                     return fail(c, DOPF_E_INVALID, "peer exchange: rank %d joins after %llu iterations, this rank after %llu — the ranks "
                                 "must join with the same iteration count", r, hello[r] - 1ull, one - 1ull);
+                }
             break;
         }
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_s)
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_s) {
+            xchg_undo(c, cs);
             return fail(c, DOPF_E_DEVICE, "peer exchange: %d of %d ranks showed up within %.0f s", seen, world, wait_s);
+        }
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
     drop_graphs(c);

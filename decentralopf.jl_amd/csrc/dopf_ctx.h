@@ -29,6 +29,7 @@ struct dopf_ctx {
     unsigned long long quiet_parked = 0;    // times the quiet chain parked itself (a line got flagged) and the host went back
     std::vector<void *> allocs;
     void *own_cons = nullptr;
+    double *getter_scratch = nullptr;      // 3 * N * T doubles, allocated at the first getter that needs them (freed with the context)
     std::vector<int> gen_perm, sto_perm;   // sorted position -> caller's index
     dopf::Status host_st{};
     dopf::Status *host_pin = nullptr;       // page-locked landing area of the status read-back (a pageable target is staged: slower)

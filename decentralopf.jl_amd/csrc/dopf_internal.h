@@ -17,10 +17,19 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/dopf.h"
 
 namespace dopf {
+
+// Tuning knobs of the experiments (item counts, block counts, launch splits) are environment variables
+// of builds with -DDOPF_EXPERIMENTS only; the shipped library does not change kernel selection on ambient environment.
+#ifdef DOPF_EXPERIMENTS
+inline const char *exp_env(const char *name) { return getenv(name); }
+#else
+inline const char *exp_env(const char *) { return nullptr; }
+#endif
 
 // one block's share of the agent list: agents [a0, a1) all sit at `node`
 struct Item {
@@ -240,6 +249,7 @@ void launch_dual(const DevView &v, hipStream_t s, const XchgView *xd = nullptr);
 //      // consensus -> duals, residuals, prices, status
 void launch_derive(const DevView &v, hipStream_t s, bool from_primal);
 void launch_derive_level(const DevView &v, hipStream_t s);            // E = cumsum(C - D) into v.E
+void launch_penalty_sums(const DevView &v, double *out /* [3][N][T], device */, hipStream_t s);   // Result.penalty_term, per node
 void launch_node_results(const DevView &v, double *gen, double *dis, double *chg, hipStream_t s);   // [n + N*t] each, device pointers   // consensus -> inj/s/flow/price (no dual step)
 
 }  // namespace dopf

@@ -163,7 +163,11 @@ __device__ DOPF_TAIL_INLINE void tail_block(const DevView *self)
             const int W = x.world, rk = x.me;
             const unsigned long long seq = (unsigned long long)v.st->iters_total + 1ull;
             const size_t xpar = (size_t)(seq & 1ull), n = x.n;
-            if (act && !half)
+            // A rank whose OWN sums did not arrive in time (badT & 1) sends nothing and publishes no flag: its peers then fail in
+            // this same iteration (their wait for this rank's flag is bounded) instead of running a dual step on a partial vector.
+            __syncthreads();
+            const bool localBad = (badT & 1) != 0;
+            if (act && !half && !localBad)
                 for (int q = 0; q < W; ++q) {
                     const int r = (rk + 1 + q) % W;                    // the peers first, the own slot last
                     x.data[r][(xpar * W + rk) * n + t] = xsum;
@@ -171,7 +175,7 @@ __device__ DOPF_TAIL_INLINE void tail_block(const DevView *self)
             __threadfence_system();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid < W) {
+            if (tid < W && !localBad) {
                 __hip_atomic_store(x.flags[tid] + (xpar * W + rk) * x.nchunks, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 const unsigned long long *f = x.flags[rk] + (xpar * W + tid) * x.nchunks;
                 const unsigned long long w0 = wall_clock64();
@@ -215,7 +219,8 @@ __device__ DOPF_TAIL_INLINE void tail_block(const DevView *self)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (only LDS data crosses: the stores above need not be acknowledged first)
     DOPF_TAIL_STAMP(3)
     if (tid == 0) {
-        if (badT & 2) { v.st->xchg_timeout = 1; return; }                       // a peer's part did not arrive (sticky; DOPF_E_DEVICE)
+        if (badT & 2) { v.st->xchg_timeout = 1; v.st->halt = 1; return; }       // a peer's part did not arrive (sticky; DOPF_E_DEVICE): the chain
+                                                                                // stops here — the rest of the graph would add into this accumulator set again
         if (badT) { v.st->tail_timeout = 1; v.st->halt = 1; return; }           // (sticky; the host reports DOPF_E_DEVICE)
         double r0 = 0.0;
         for (int q = 0; q < nth / 64; ++q) r0 = fmax(r0, wmaxT[q]);

@@ -13,6 +13,8 @@
 //   k_derive_* rebuild the consensus state from a primal state handed in by dopf_set_state
 #include <algorithm>
 
+#include <atomic>
+
 #include "dopf_internal.h"
 
 namespace dopf {
@@ -186,15 +188,24 @@ __global__ __launch_bounds__(64) void k_tables(DevView v)
     build_table(v, n, t, shm);
 }
 
+// A function attribute belongs to the CURRENT device: "raised once per process" leaves every other device of a dopf_multi_* run
+// (or of a process with contexts on several GPUs) at the default limit, and the launch fails there. One bit per device, under a
+// lock (for_each_shard launches from one host thread per shard).
+static bool first_time_on_this_device(std::atomic<unsigned long long> &mask)
+{
+    int dev = 0;
+    hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    return (mask.fetch_or(bit) & bit) == 0ull;
+}
+
 void launch_tables(const DevView &v, hipStream_t s)
 {
     if (v.L == 0 || v.tablesInDual) return;  // (tablesInDual: the dual/price kernel builds the tables of its timestep itself)
     const size_t shm = (size_t)(4 * v.M2 + 1) * sizeof(double);
-    static bool big_lds = false;
-    if (shm > 64 * 1024 && !big_lds) {     // worst case (every kink inside the window) needs 4 * 2L doubles
+    static std::atomic<unsigned long long> big_lds{0ull};
+    if (shm > 64 * 1024 && first_time_on_this_device(big_lds))     // worst case (every kink inside the window) needs 4 * 2L doubles
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_tables), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        big_lds = true;
-    }
     hipLaunchKernelGGL(k_tables, dim3(v.N * v.T), dim3(64), shm, s, v);
 }
 
@@ -1676,13 +1687,12 @@ __global__ __launch_bounds__(256) void k_dual_price_small(DevView v, XchgView x)
 static size_t t1024_lds(const DevView &v)
 {
     const size_t bytes = (4 * (size_t)v.N + 3 * (size_t)v.L + (size_t)v.tablesInDual * (4 * (size_t)v.M2 + 1)) * sizeof(double);
-    static bool raised = false;
-    if (bytes > 48 * 1024 && !raised) {
+    static std::atomic<unsigned long long> raised{0ull};
+    if (bytes > 48 * 1024 && first_time_on_this_device(raised)) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_dual_price_t1024<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_dual_price_t1024<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_dual_price_t1024<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_dual_price_t1024<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        raised = true;
     }
     return bytes;
 }
@@ -1766,6 +1776,47 @@ __global__ __launch_bounds__(256) void k_node_results(DevView v, double *gen, do
 void launch_derive_level(const DevView &v, hipStream_t s)
 {
     if (v.S > 0) hipLaunchKernelGGL(k_derive_level, dim3((unsigned)((v.S + 255) / 256)), dim3(256), 0, s, v);
+}
+
+// Result.penalty_term (reference src/structures/results.jl:66-70 with sum_up, src/helpers/penalty_terms.jl:1-6): the three
+// penalty vectors of src/optimization/penalty_terms.jl:3-37 summed over ALL agents, from the injection changes the last
+// x-update left on the device (dltG / dltS: networks with DOPF_F_KEEP_DELTAS) and the consensus state that solve read. One
+// block per (node, 64 timesteps), thread = timestep: the node's agents are walked in list order and, per agent, the lines in
+// order — dopf_get_agent_penalty's arithmetic, agent by agent — then the host adds the N rows in node order.
+__global__ __launch_bounds__(64) void k_penalty_sums(DevView v, double *out /* [3][N][T] */)
+{
+    const int TB = (v.T + 63) / 64;
+    const int n = blockIdx.x / TB, t = (blockIdx.x % TB) * 64 + threadIdx.x;
+    if (t >= v.T) return;
+    const int L = v.L, T = v.T;
+    const double w2 = 2.0 * v.w_flow, g = v.gamma, s = v.s_used[t];
+    double eb = 0.0, up = 0.0, lo = 0.0;
+    for (int kind = 0; kind < 2; ++kind) {
+        const int *beg = kind == 0 ? v.node_gen_beg : v.node_sto_beg;
+        const double *dlt = kind == 0 ? v.dltG : v.dltS;
+        for (int a = beg[n]; a < beg[n + 1]; ++a) {
+            const double dl = dlt[(size_t)a * T + t];
+            eb += (s + dl) * (s + dl);                                               // penalty_terms.jl:3-7
+            double au = 0.0, al = 0.0;
+            for (int l = 0; l < L; ++l) {
+                const size_t i = l + (size_t)L * t;
+                const double F = v.fmax[l];
+                const double fl = v.flow_used[i] + v.ptdf[l + (size_t)L * n] * dl;
+                const double u = fmax(0.0, (g * v.avgU_used[i] - w2 * (fl - F)) / (w2 + g));
+                const double k = fmax(0.0, (g * v.avgK_used[i] + w2 * (fl + F)) / (w2 + g));
+                au += (fl + u - F) * (fl + u - F);                                    // penalty_terms.jl:10-20
+                al += (k - fl - F) * (k - fl - F);                                    // :23-37
+            }
+            up += au; lo += al;
+        }
+    }
+    const size_t NT = (size_t)v.N * T, at = (size_t)n * T + t;
+    out[at] = eb; out[NT + at] = up; out[2 * NT + at] = lo;
+}
+
+void launch_penalty_sums(const DevView &v, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_penalty_sums, dim3(v.N * ((v.T + 63) / 64)), dim3(64), 0, s, v, out);
 }
 
 void launch_node_results(const DevView &v, double *gen, double *dis, double *chg, hipStream_t s)

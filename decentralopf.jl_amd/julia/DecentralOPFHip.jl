@@ -230,6 +230,18 @@ function dopf_result(admm::ADMM)
             line_utilization=fl, total_costs=cost[], node_generation=ng, node_discharge=nd, node_charge=nc)
 end
 
+"""
+Result.penalty_term of the last solved iteration (src/structures/results.jl:66-70: the units' PenaltyTerms summed,
+src/helpers/penalty_terms.jl:1-6) as `(energy_balance, upper_flow, lower_flow)`, T values each — one pass on the device.
+Needs lines and `flags` containing DOPF_F_KEEP_DELTAS at construction (the device then keeps every unit's injection change).
+"""
+function dopf_penalty_sums(admm::ADMM)
+    T = length(admm.T)
+    pen = zeros(3 * T)
+    dopf_check(ccall((:dopf_get_penalty_sums, DOPF_LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), admm.ctx, pen), admm.ctx)
+    return (energy_balance=pen[1:T], upper_flow=pen[T+1:2T], lower_flow=pen[2T+1:3T])
+end
+
 # after a batch of iterations: iteration counter, stop flags, the dual sets get_nodal_price needs
 function dopf_refresh!(admm::ADMM, converged::Bool)
     a = Ref{Cdouble}(0.0); b = Ref{Cdouble}(0.0); c = Ref{Cdouble}(0.0); it = Ref{Cint}(0)

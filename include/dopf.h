@@ -123,6 +123,20 @@ typedef struct dopf_params {
                                    latency in front, no status read-back behind) */
 #define DOPF_F_STO_GENERAL 16384 /* storages: the general active-set body (kernels_agents.hip: sto_warm_body) also where the lean
                                   * copper-plate body (sto_lean.h) applies — the two are compared by the tests */
+#define DOPF_F_NO_QUIET   32768 /* networks, single-GPU chain: always launch k_slack (never the "quiet" chain, in which the dual/price
+                                  * kernel forms the node sums while no line is flagged); bitwise comparisons of the two chains */
+#define DOPF_F_XCHG_OWNER 65536 /* peer exchange: always the reduce-scatter + all-gather form (every chunk has an owner rank that adds the
+                                  * ranks' copies), also for vectors of one chunk per rank — by default the library picks it when the
+                                  * vector has more chunks than ranks */
+#define DOPF_F_XCHG_ALLGATHER 131072 /* peer exchange: always the all-gather form (every rank stores its vector into every peer's area) */
+#define DOPF_F_NO_TAIL_XCHG 262144 /* copper plates on a peer exchange: the exchange runs inside the one-block dual kernel of the
+                                  * three-launch chain instead of inside the tail block of the one-launch iteration */
+#define DOPF_F_NET_SMALL_ITEMS 524288 /* networks, one launch for all agents: cut the generators into the ~1024 items the separate
+                                  * launches use instead of ~512 larger ones (same partial-sum rows on both chains: bitwise comparisons) */
+/* Everything else that steers kernel selection is decided from the problem's shape ("which chain runs"). The
+ * library reads two environment variables, neither of which changes results: DOPF_GUARD (debug allocator) and DOPF_XCHG_TIMEOUT_MS
+ * (how long an exchange kernel waits for a lost peer). Tuning knobs of the experiments (item counts, block counts, launch splits)
+ * exist only in builds with -DDOPF_EXPERIMENTS. */
 #define DOPF_F_DEBUG_LEAVE  2048  /* tests: the active-set storage body declares every third storage uncertified, so that the
                                    hand-over to the scan body is exercised in every kernel variant                        */
 #define DOPF_F_DEBUG_ROOT_CAP 128 /* tests: the scan kernel's root search gives up after 2 iterations instead of
@@ -185,6 +199,12 @@ int dopf_get_agent_slacks(dopf_ctx *ctx, int32_t agent, double *U, double *K);
  * with print_penalty=true. delta = the agent's injection change of the last iteration (T values), or NULL to
  * use the device's copy, which exists only with lines and DOPF_F_KEEP_DELTAS (DOPF_E_UNSUPPORTED otherwise). */
 int dopf_get_agent_penalty(dopf_ctx *ctx, int32_t agent, const double *delta, double *penalty /*3*T*/);
+/* Result.penalty_term of the last result (src/structures/results.jl:66-70: `sum_up` of src/helpers/penalty_terms.jl:1-6 over
+ * every unit's PenaltyTerm): penalty[0..T) energy_balance, [T..2T) upper_flow, [2T..3T) lower_flow, each the SUM over all
+ * agents of this context of what dopf_get_agent_penalty returns for one — one pass on the device instead of one call per
+ * agent. Needs lines and DOPF_F_KEEP_DELTAS (the injection changes of the last x-update must be on the device);
+ * DOPF_E_UNSUPPORTED otherwise. */
+int dopf_get_penalty_sums(dopf_ctx *ctx, double *penalty /*3*T*/);
 /* which = 0: duals used by the last solve (what the reference's driver script evaluates),
  * which = 1: duals after the last update. out is N x T, [n + N*t]. */
 int dopf_get_nodal_price(dopf_ctx *ctx, int32_t which, double *out);

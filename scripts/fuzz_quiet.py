@@ -1,5 +1,5 @@
 """The quiet chain (networks: no k_slack launch while no line is flagged; the dual/price kernel forms the node sums, parks the chain when
-its dual step flags a line) against the chain that always launches k_slack (DOPF_F_KEEP_DELTAS keeps a context on it): random wide
+its dual step flags a line) against the chain that always launches k_slack (DOPF_F_NO_QUIET keeps a context on it): random wide
 networks, a few hundred iterations in calls of random length, every array of the C ABI bit for bit after every call.
 usage: python scripts/fuzz_quiet.py [n_cases] [seed]"""
 import sys, os, time, ctypes as C
@@ -32,7 +32,7 @@ for k in range(n_cases):
     params = dict(gamma=float(rng.choice([1.0 / A, 0.5 / A, 2.0 / A])), w_flow=float(rng.choice([0.3 / A, 1.0 / A, 0.1 / A, 3.0 / A])),
                   eps=float(rng.choice([0.0, 0.0, 1e-3])), max_iters=int(rng.choice([0, 0, 150])))
     a = make_engine(hip, pp, **params)
-    b = make_engine(hip, pp, flags=_capi.F_KEEP_DELTAS, **params)
+    b = make_engine(hip, pp, flags=_capi.F_NO_QUIET, **params)          # the chain the quiet one replaces: k_slack in every iteration
     q = (C.c_int64 * 3)()
     ok, was_quiet = True, 0
     done = 0
@@ -46,10 +46,8 @@ for k in range(n_cases):
             print("MISMATCH (status)", case, params, done, ra, rb, a.get_residuals(), b.get_residuals(), flush=True); ok = False; break
         sa, sb = state_of(a), state_of(b)
         for key in sa:
-            if key != "cost" and sa[key].size and not np.array_equal(sa[key], sb[key]):
+            if sa[key].size and not np.array_equal(sa[key], sb[key]):           # (the cost too: both chains add it in the same order)
                 print("MISMATCH", case, params, done, key, float(np.abs(sa[key] - sb[key]).max()), flush=True); ok = False; break
-        if abs(sa["cost"][0] - sb["cost"][0]) > 1e-12 * abs(sb["cost"][0]):
-            print("MISMATCH cost", case, params, done, flush=True); ok = False
         if ra[1]:
             break
     hip.lib.dopf_debug_quiet(a._ctx, q)

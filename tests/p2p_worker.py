@@ -25,7 +25,7 @@ CASES = {
 KEYS = ("lam", "mu", "rho", "inj", "avg_U", "avg_K", "flow", "cost")
 
 
-def compare(pp, n, steps, kw, tol):
+def compare(pp, n, steps, kw, tol, xflags=0):
     ref = make_engine(hip, pp, **kw)
     wants = []
     for k in steps:
@@ -33,7 +33,7 @@ def compare(pp, n, steps, kw, tol):
         wants.append(state_of(ref))
     ref.close()
     gc.collect()
-    m = _capi.MultiEngine(hip, n, params=_capi.default_params(flags=_capi.F_COMM_P2P, **kw), devices=[0] * n, **pp.engine_kwargs())
+    m = _capi.MultiEngine(hip, n, params=_capi.default_params(flags=_capi.F_COMM_P2P | xflags, **kw), devices=[0] * n, **pp.engine_kwargs())
     assert m.shard(0).comm_info()[0] == n
     for k, want in zip(steps, wants):
         assert m.iterate(k) == (k, False)
@@ -61,11 +61,9 @@ for name, case in CASES.items():
 
 # copper plates above ran the exchange inside the tail block of the one-launch iteration; the older place —
 # inside the one-block dual kernel of the three-launch chain — stays reachable and tested
-os.environ["DOPF_NO_TAIL_XCHG"] = "1"
 kwc = dict(CASES["copper plate T96"])
 ppc = synth.synthetic_case(kwc.pop("n_gen"), kwc.pop("n_sto"), kwc.pop("T"), **kwc)
-compare(ppc, 2, (1, 7, 30), dict(eps=0.0, gamma=1.0 / (ppc.G + ppc.S)), 1e-9)
-del os.environ["DOPF_NO_TAIL_XCHG"]
+compare(ppc, 2, (1, 7, 30), dict(eps=0.0, gamma=1.0 / (ppc.G + ppc.S)), 1e-9, xflags=_capi.F_NO_TAIL_XCHG)
 print("three-launch exchange ok", flush=True)
 
 # a consensus vector of several chunks (30 nodes, 50 lines, 24 steps: 3 121 doubles), three shards
@@ -78,13 +76,11 @@ print("chunks ok", flush=True)
 # the reduce-scatter + all-gather form of the exchange (every chunk has an owner that adds the ranks' copies and hands the
 # sum to everybody): forced on the cases above, and chosen by the library itself on a vector of more than one chunk per
 # shard (40 nodes, 60 lines, 48 steps: 7 681 doubles = 4 chunks, three shards)
-os.environ["DOPF_XCHG_REDUCE_SCATTER"] = "1"
-compare(pp, 3, (1, 5, 21), dict(eps=0.0, gamma=1.0 / A, w_flow=0.3 / A), 1e-8)
+compare(pp, 3, (1, 5, 21), dict(eps=0.0, gamma=1.0 / A, w_flow=0.3 / A), 1e-8, xflags=_capi.F_XCHG_OWNER)
 kwn = dict(CASES["network"])
 ppn = synth.synthetic_case(kwn.pop("n_gen"), kwn.pop("n_sto"), kwn.pop("T"), **kwn)
 for n in (2, 3):
-    compare(ppn, n, (1, 4, 7), dict(eps=0.0, gamma=0.01), 1e-9)
-del os.environ["DOPF_XCHG_REDUCE_SCATTER"]
+    compare(ppn, n, (1, 4, 7), dict(eps=0.0, gamma=0.01), 1e-9, xflags=_capi.F_XCHG_OWNER)
 pp4 = synth.synthetic_case(320, 40, 48, N=40, L=60, seed=43, fmax_factor=0.7, fmax_min=5)
 A4 = pp4.G + pp4.S
 assert (pp4.N * pp4.T + 2 * pp4.L * pp4.T + 1 + 2047) // 2048 > 3

@@ -1,6 +1,6 @@
 """One rank of a multi-process HIP run with the in-library communicator (dopf_comm_init): started by
 tests/test_gpu_multi.py, one process per GPU (or per rank on one GPU for the peer exchange). argv: rank world id_file out_file
-n_iters [rccl|xchg]"""
+n_iters [rccl|xchg] [extra DOPF_F_* flags]"""
 import os
 import sys
 import time
@@ -18,11 +18,12 @@ from helpers import make_engine, state_of  # noqa: E402
 
 rank, world, id_file, out_file, n_iters = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5])
 transport = sys.argv[6] if len(sys.argv) > 6 else "rccl"
+xflags = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 import torch  # noqa: E402,F401  (before the library loads RCCL)
 
 pp = synth.synthetic_case(600, 80, 24, N=3, L=3, seed=11, fmax_factor=0.8, fmax_min=5)
 A = pp.G + pp.S
-e = make_engine(_capi.hip_api(), pp.shard(rank, world), eps=0.0, gamma=0.01, n_agents_global=A,
+e = make_engine(_capi.hip_api(), pp.shard(rank, world), eps=0.0, gamma=0.01, n_agents_global=A, flags=xflags,
                 device=rank % torch.cuda.device_count())
 
 

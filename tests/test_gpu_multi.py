@@ -138,6 +138,13 @@ def test_agent_slacks_penalties_and_residual_vectors(hip_api, oracle_api):
             assert np.abs(lo - ((K - fl - pp.f_max[:, None]) ** 2).sum(axis=0)).max() < 1e-6 * max(1.0, lo.max())
             eb2, _, _ = h.get_agent_penalty(a, delta=d)         # same with the change passed in
             assert np.abs(eb2 - eb).max() < 1e-9 * max(1.0, eb.max())
+        # Result.penalty_term (results.jl:66-70): the sum over ALL agents in one device pass = the per-agent terms added up
+        eb_s, up_s, lo_s = h.get_penalty_sums()
+        acc = np.zeros((3, pp.T))
+        for a in range(pp.G + pp.S):
+            acc += np.asarray(h.get_agent_penalty(a))
+        for got, want in zip((eb_s, up_s, lo_s), acc):
+            assert np.abs(got - want).max() <= 1e-10 * max(1.0, np.abs(want).max())
         lam1, mu1, rho1 = h.get_duals()
         rl, rm, rr = h.get_residual_vectors()
         assert np.array_equal(rl, np.abs(lam1 - lam0)) and np.array_equal(rm, np.abs(mu1 - mu0)) and np.array_equal(rr, np.abs(rho1 - rho0))
@@ -153,6 +160,8 @@ def test_agent_slacks_penalties_and_residual_vectors(hip_api, oracle_api):
     assert np.allclose(e.get_agent_penalty(2, delta=d)[0], (s0 + d) ** 2)
     with pytest.raises(_capi.DopfError):
         e.get_agent_penalty(2)
+    with pytest.raises(_capi.DopfError):          # no lines: the device does not keep the agents' changes
+        e.get_penalty_sums()
 
 
 def test_two_ranks_two_gpus_rccl(hip_api, tmp_path):
@@ -185,6 +194,31 @@ def test_two_ranks_two_gpus_rccl(hip_api, tmp_path):
     assert outs[0]["comm"][0] == 2
 
 
+@pytest.mark.parametrize("transport", ["rccl", "p2p"])
+def test_multi_network_on_two_devices(hip_api, transport):
+    """dopf_multi_* with one shard per DEVICE on a network whose dual/price kernel needs the raised dynamic-LDS limit
+    (118 nodes / 186 lines: ~90 KB): the limit is a per-device function attribute — raised once per process it was missing on
+    every device but the first (advisor, round 3). Needs two devices (skips on the one-GPU box)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    pp = synth.baseline_config(3, scale=0.02)
+    A = pp.G + pp.S
+    kw = dict(eps=0.0, gamma=1.0 / A, w_flow=0.3 / A)
+    ref = make_engine(hip_api, pp, **kw)
+    ref.iterate(12)
+    want = state_of(ref)
+    m = _capi.MultiEngine(hip_api, 2, params=_capi.default_params(flags=_capi.F_COMM_P2P if transport == "p2p" else 0, **kw),
+                          devices=[0, 1], **pp.engine_kwargs())
+    assert m.iterate(12) == (12, False)
+    for i in range(2):
+        got = state_of(m.shard(i))
+        for key in ("lam", "mu", "rho", "inj", "avg_U", "avg_K", "flow"):
+            if want[key].size:
+                assert np.abs(got[key] - want[key]).max() <= 1e-8 * max(1.0, np.abs(want[key]).max()), (key, i)
+    m.close()
+
+
 def test_peer_exchange_shards_on_one_device(hip_api):
     """DOPF_F_COMM_P2P through dopf_multi_*: the consensus sum by the exchange kernels (every shard stores its vector into
     every shard's receive area, flags, sum in rank order), inside the iteration graphs, each shard on its own stream and
@@ -210,9 +244,8 @@ def test_ranks_in_separate_processes_peer_exchange(hip_api, tmp_path, world, for
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rank_worker.py")
     idf = str(tmp_path / "handle")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DOPF_XCHG_TIMEOUT_MS="20000")
-    if form == "reduce-scatter":
-        env["DOPF_XCHG_REDUCE_SCATTER"] = "1"
-    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), idf, str(tmp_path / f"out{r}.npz"), "25", "xchg"], env=env)
+    xflags = str(_capi.F_XCHG_OWNER if form == "reduce-scatter" else 0)
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), idf, str(tmp_path / f"out{r}.npz"), "25", "xchg", xflags], env=env)
              for r in range(world)]
     try:
         for p in procs:

@@ -386,6 +386,33 @@ def test_hip_tail_in_the_launch_matches_the_three_launch_chain(hip_api, name, ma
     assert abs(c.get_consensus()[4] - d.get_consensus()[4]) <= 1e-9 * abs(d.get_consensus()[4])
 
 
+@pytest.mark.parametrize("scale", [2.0 ** 24, 2.0 ** 27, 2.0 ** 28, 2.0 ** 29, 2.0 ** 32], ids=lambda x: f"pmax x 2^{int(np.log2(x))}")
+def test_hip_fixed_point_sums_at_the_admission_edge(hip_api, scale):
+    """The one-launch iteration adds the blocks' sums as fixed-point integers whose binary point comes from the problem's
+    bounds (k = 52 - ceil(log2(sum pmax)) fraction bits; dopf_create admits the tail only while k >= 8). Units scaled so that
+    k lands near that edge — 2^-19 ... 2^-8 MW per contribution and beyond: either the tail is in the launch and the iterates
+    follow the fp64 chain (DOPF_F_NO_TAIL_FUSE) to 1e-9 of their size, or the library has put the case on the fp64 chain."""
+    pp = synth.synthetic_case(300, 30, 24, seed=77)
+    for arr in (pp.gen_pmax, pp.sto_pmax, pp.sto_emax, pp.demand):
+        arr *= scale
+    k = 52 - int(np.ceil(np.log2(1.0 + pp.gen_pmax.sum() + pp.sto_pmax.sum())))
+    g = 1.0 / (pp.G + pp.S)
+    a = make_engine(hip_api, pp, eps=0.0, gamma=g)
+    b = make_engine(hip_api, pp, eps=0.0, gamma=g, flags=_capi.F_NO_TAIL_FUSE)
+    fused = a.iterate_timed(1)["tail_fused"]
+    b.iterate(1)
+    assert fused == (1 if k >= 8 else 0), (k, fused)
+    assert {2.0 ** 24: 12, 2.0 ** 27: 9, 2.0 ** 28: 8, 2.0 ** 29: 7, 2.0 ** 32: 4}[scale] == k       # the sweep sits on the edge (k = 8) and on both sides
+    for n in (1, 6, 40):
+        a.iterate(n)
+        b.iterate(n)
+        sa, sb = state_of(a), state_of(b)
+        for key in sa:
+            if sa[key].size:
+                assert np.abs(sa[key] - sb[key]).max() <= 1e-9 * (1.0 + np.abs(sb[key]).max()), (k, n, key)
+    assert a.solver_failures() == 0 and b.solver_failures() == 0
+
+
 SLACK_IN_DUAL = [
     ("30 nodes / 45 lines, limits binding", lambda: synth.synthetic_case(500, 50, 168, N=30, L=45, seed=11, fmax_factor=1.0, fmax_min=20), 0.3),
     ("30 nodes / 45 lines, literal flow weight", lambda: synth.synthetic_case(500, 50, 168, N=30, L=45, seed=12), None),
@@ -402,13 +429,12 @@ def test_hip_slack_sums_in_the_dual_launch_are_bit_identical(hip_api, monkeypatc
     generator kernel, storage kernel, k_slack, k_reduce, dual): every array the C ABI exposes is bit-identical at every step,
     through the cold start (lines whose switch point lies inside a node's window: the agent-by-agent sums) and after.
     (Same generator items on both sides: the one-launch form would take half as many, twice as large.)"""
-    monkeypatch.setenv("DOPF_GEN_TARGET_ITEMS", "512")
     pp = make()
     A = pp.G + pp.S
     kw = dict(eps=0.0, gamma=1.0 / A)
     if wf is not None:
         kw["w_flow"] = wf / A
-    a = make_engine(hip_api, pp, **kw)
+    a = make_engine(hip_api, pp, flags=_capi.F_NET_SMALL_ITEMS, **kw)
     b = make_engine(hip_api, pp, flags=_capi.F_NO_TAIL_FUSE | _capi.F_NO_FUSE, **kw)
     assert a.iterate_timed(1)["agents_fused"] == 1 and b.iterate_timed(1)["agents_fused"] == 0
     for n in (1, 3, 20, 100):
