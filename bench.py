@@ -57,7 +57,7 @@ PEAK_GBPS = 8000.0        # HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the 
 
 def pmc_iteration_traffic(wl_):
     """HBM bytes of ONE iteration (all kernels of the chain) from the committed PMC passes, or None"""
-    for tag in ("r03", "r02"):
+    for tag in ("r04", "r03", "r02"):
         f_ = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
         if os.path.exists(f_):
             recs = {k: r for k, r in json.load(open(f_)).get(wl_, {}).items()
@@ -83,6 +83,35 @@ def algorithmic_bytes(G, S, T, N, L):
     sto = S * (40 * T + 28)
     shared = (N + 5 * L + 2) * 8 * T
     return gen, sto, shared
+
+
+def bytes_moved(G, S, T, N, L):
+    """What the kernels of this build actually move of the model above: the storage level E = cumsum(C - D) is not stored by
+    the solve any more (nothing on the path reads it back; dopf_get_primal rebuilds it on request) — 32T+28 B per storage
+    update instead of 40T+28. (Row skipping moves fewer generator bytes still: that is `traffic`, measured.)"""
+    gen, sto, shared = algorithmic_bytes(G, S, T, N, L)
+    return gen, S * (32 * T + 28), shared
+
+
+def valu_roofline(workload, kernel_prefix, kernel_ms):
+    """The VALU bound of a kernel next to its HBM bound: vector instructions per launch x 4 cycles (the issue rate of a wave64
+    fp64 instruction on a SIMD, measured 4.0x for every kernel here) / (1024 SIMDs x 2.4 GHz) = the time the chip's vector
+    pipes need for them at full occupancy and maximum clock; `frac` = that / the kernel's duration. Instruction counts from the
+    committed counter passes (profiles/<tag>_valu.json: rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES ..., scripts/prof_pmc.sh)."""
+    for tag in ("r04", "r03"):
+        f_ = os.path.join(ROOT, "profiles", f"{tag}_valu.json")
+        if not os.path.exists(f_):
+            continue
+        recs = json.load(open(f_)).get(workload, {})
+        rec = next((r for k, r in sorted(recs.items()) if k.startswith(kernel_prefix) and r.get("SQ_INSTS_VALU")), None)
+        if rec:
+            n = rec["SQ_INSTS_VALU"]
+            t_min_ms = n * 4.0 / (1024 * 2.4e9) * 1e3
+            return {"bound": "valu", "valu_instructions_per_launch": n, "valu_instructions_per_wave": n / max(rec.get("SQ_WAVES", 1.0), 1.0),
+                    "cycles_per_instruction": 4.0, "simds": 1024, "clock_GHz": 2.4, "min_ms": t_min_ms, "kernel_ms": kernel_ms,
+                    "frac": t_min_ms / kernel_ms if kernel_ms else None,
+                    "source": f"profiles/{tag}_valu.json (counter passes of `bench.py --workload {workload}`, mean per launch — not measured in this run)"}
+    return None
 
 
 def cpu_baseline(pp, gamma, w_flow, synth, budget_s=14.0):
@@ -526,6 +555,7 @@ def main():
 
     if rank == 0:
         gen_b, sto_b, shared_b = algorithmic_bytes(pp.G, pp.S, pp.T, pp.N, pp.L)
+        sto_mv = bytes_moved(pp.G, pp.S, pp.T, pp.N, pp.L)[1]
         out = {
             "metric": "agent_subproblem_updates_per_sec", "value": A_global * args.steps / dt,
             "unit": "agent-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -578,7 +608,7 @@ def main():
             # one launch per iteration: the per-iteration time of the graph replay IS the launch (plus its one kernel boundary)
             k_ms = ref_it_ms if one_launch else max(timing["gen_ms"] - ov, 1e-6)
             traffic, traffic_source = None, None       # HBM bytes per launch from the committed PMC passes (scripts/profile.sh)
-            for tag in ("r03", "r02", "r01"):
+            for tag in ("r04", "r03", "r02", "r01"):
                 pmc_file = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
                 if traffic is None and os.path.exists(pmc_file):
                     recs = json.load(open(pmc_file)).get(args.workload, {})
@@ -602,6 +632,8 @@ def main():
                                "unit": "GB/s", "frac": ach / PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                                "bytes_basis": basis,
                                "algorithmic_bytes_per_launch": alg_b,
+                               "algorithmic_bytes_moved": alg_b - (sto_b - sto_mv) if fused else alg_b,
+                               "frac_of_bytes_moved": (alg_b - (sto_b - sto_mv) if fused else alg_b) / (k_ms * 1e-3) / 1e9 / PEAK_GBPS,
                                "kernel_ms": k_ms,
                                "kernel_ms_basis": ("device-side per-iteration time of the timed region's graph replay (events around the call's launches, "
                                                    "DOPF_F_TIME_CALLS): the iteration is this ONE launch (x-updates, consensus sum, dual step, stop test) "
@@ -618,6 +650,9 @@ def main():
                                                    "frac": whole_b / it_ms * 1e-6 / PEAK_GBPS,
                                                    "what": "algorithmic bytes of one iteration / per-iteration time of the timed region "
                                                            "(all launches and the gaps between them)"}}
+            vr = valu_roofline(args.workload, "k_agents" if (fused and pp.L == 0) else ("k_net_agents" if fused else kname), k_ms)
+            if vr:
+                out["roofline"]["valu"] = vr
             if row_skip:
                 out["roofline"]["algorithmic_GBps"] = alg_b / (k_ms * 1e-3) / 1e9
                 trf_all, src_all = pmc_iteration_traffic(args.workload)
@@ -637,8 +672,9 @@ def main():
                 out["storage_kernel"] = {"kernel": "k_sto (active-set solve; scan kernel for what it leaves over" +
                                                    ("; carries the iteration's tail block)" if tail else ")") if pp.L == 0 else "k_sto_warm + k_sto_update",
                                          "bound": "fp64 VALU (segmented Newton + certificate), not HBM",
-                                         "algorithmic_bytes_per_launch": sto_b, "kernel_ms": s_ms,
-                                         "achieved_GBps": sto_b / s_ms * 1e-6, "frac_of_hbm_peak": sto_b / s_ms * 1e-6 / PEAK_GBPS}
+                                         "algorithmic_bytes_per_launch": sto_b, "algorithmic_bytes_moved": sto_mv, "kernel_ms": s_ms,
+                                         "achieved_GBps": sto_b / s_ms * 1e-6, "frac_of_hbm_peak": sto_b / s_ms * 1e-6 / PEAK_GBPS,
+                                         "valu": valu_roofline(args.workload, "k_sto", s_ms)}
             if fused and world == 1 and not args.force_sharded and not args.no_side:
                 # the two halves of k_agents on their own (separate launches, DOPF_F_NO_FUSE), steady state: the generator
                 # sweep is the HBM-bound part, the storage solve the VALU-bound one
@@ -719,11 +755,16 @@ def main():
                 ex.iterate(nx)
                 tx = time.perf_counter() - t0
                 gb, sb, shb = algorithmic_bytes(ppx.G, ppx.S, ppx.T, ppx.N, ppx.L)
+                skips = wl in ("config4", "config4x2")      # (row skipping: the model's bytes are not moved — see hbm_traffic_* below)
+                key = "model_bytes" if skips else "whole_iteration"
                 also.append({"workload": wl, "agents": Ax, "timesteps": ppx.T, "iters_per_sec": nx / tx,
                              "agent_updates_per_sec": Ax * nx / tx, "ms_per_step": 1e3 * tx / nx,
-                             "whole_iteration_GBps": (gb + sb + shb) / (tx / nx) / 1e9,
-                             "whole_iteration_frac_of_peak": (gb + sb + shb) / (tx / nx) / 1e9 / PEAK_GBPS,
+                             key + "_GBps": (gb + sb + shb) / (tx / nx) / 1e9,
+                             key + "_frac_of_peak": (gb + sb + shb) / (tx / nx) / 1e9 / PEAK_GBPS,
                              "window": f"iterations {wx + 1}..{wx + nx}"})
+                if skips:
+                    also[-1]["model_bytes_note"] = ("SURVEY 8d's bytes per update x updates / time: NOT a bandwidth — the generator sweep skips "
+                                                    "rows parked on a bound, so these bytes are not moved; hbm_traffic_frac_of_peak is the measured one")
                 if wl in ("config4", "config4x2"):
                     # row skipping moves fewer bytes than the model; config4x2's arrays (384 MB of P) do not fit the 256 MiB Infinity
                     # Cache: there "fraction of HBM peak" means HBM. Bytes from the committed PMC passes, time from this run.

@@ -127,13 +127,17 @@ static bool tail_fused(const dopf_ctx *c, bool single)
     return single && c->v.tailDev != nullptr && (c->comm == nullptr || c->tail_xchg);
 }
 
-void enqueue_local(dopf_ctx *c, bool single, bool quiet)
+// comm_quiet: a context on a peer exchange, networks whose dual step is the one-launch kernel, no line flagged at the last look
+// (dopf_iterate): the single-GPU three-launch chain with the exchange of the node sums between k_slack and the dual/price
+// kernel — no k_reduce launch (DevView::slackGlobal)
+void enqueue_local(dopf_ctx *c, bool single, bool quiet, bool comm_quiet)
 {
     DevView v = c->v;
     v.sliceDual = slice_dual(v, single) ? 1 : 0;
     v.tail = tail_fused(c, single) ? v.tailDev : nullptr;
-    v.slackInDual = single && v.slackDualOk;
-    v.quiet = v.slackInDual && quiet;
+    v.slackInDual = (single || comm_quiet) && v.slackDualOk;
+    v.slackGlobal = comm_quiet ? 1 : 0;
+    v.quiet = single && v.slackInDual && quiet;
     launch_tables(v, c->main);
     const bool fork = v.nGenItems > 0 && v.nStoItems > 0 && (c->q.flags & DOPF_F_OVERLAP_AGENTS);
     if (v.fuseAgents) {
@@ -156,13 +160,14 @@ void enqueue_local(dopf_ctx *c, bool single, bool quiet)
     if (!v.slackInDual) launch_reduce(v, c->main);
 }
 
-void enqueue_apply(dopf_ctx *c, bool single, const XchgView *xd, bool quiet)
+void enqueue_apply(dopf_ctx *c, bool single, const XchgView *xd, bool quiet, bool comm_quiet)
 {
     if (tail_fused(c, single)) return;
     DevView v = c->v;
     v.sliceDual = slice_dual(v, single) ? 1 : 0;
-    v.slackInDual = single && v.slackDualOk;
-    v.quiet = v.slackInDual && quiet;
+    v.slackInDual = (single || comm_quiet) && v.slackDualOk;
+    v.slackGlobal = comm_quiet ? 1 : 0;
+    v.quiet = single && v.slackInDual && quiet;
     launch_dual(v, c->main, xd);
 }
 
@@ -207,9 +212,14 @@ int enqueue_iteration(dopf_ctx *c, bool quiet = false)
     const XchgView *xd = comm_xchg(c);
     if (xd && !(c->v.L == 0 && slice_dual(c->v, true)) && !c->tail_xchg) xd = nullptr;
     const bool like_single = single || xd != nullptr;        // (tail_xchg: the launch's tail block exchanges; nothing else is launched)
-    enqueue_local(c, like_single, quiet && single);
-    if (!like_single) { const int rc = comm_enqueue_allreduce(c); if (rc) return rc; }
-    enqueue_apply(c, like_single, xd, quiet && single);
+    // networks on a peer exchange while no line is flagged: k_slack's node sums are exchanged, the slack sums are formed behind
+    // the exchange by the dual/price kernel — three launches + the exchange (DevView::slackGlobal)
+    const XchgView *xn = comm_xchg(c);
+    const bool comm_quiet = quiet && !like_single && xn != nullptr && c->comm_quiet_ok;
+    enqueue_local(c, like_single, quiet && single, comm_quiet);
+    if (comm_quiet) launch_xchg(c->v, *xn, c->main, true);
+    else if (!like_single) { const int rc = comm_enqueue_allreduce(c); if (rc) return rc; }
+    enqueue_apply(c, like_single, xd, quiet && single, comm_quiet);
     return DOPF_OK;
 }
 
@@ -327,6 +337,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     v.debugLeave = (q->flags & DOPF_F_DEBUG_LEAVE) ? 1 : 0;
     const int A = q->n_agents_global > 0 ? q->n_agents_global : G + S;
     v.invA = A > 0 ? 1.0 / (double)A : 0.0;
+    v.nAgents = (double)A;
     {
         const double a0 = v.w_prox + v.gamma;
         v.cp_ia = 1.0 / a0; v.cp_idet = 1.0 / (a0 * a0 - v.gamma * v.gamma); v.cp_s2 = 2.0 / (a0 + v.gamma);
@@ -540,6 +551,9 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         // ends — the node sums cost the dual kernel what k_slack and its boundary cost, 119.3 us per iteration either way)
         c->quiet_ok = v.slackDualOk && !(q->flags & DOPF_F_KEEP_DELTAS) && (max_node_rows <= 32 || exp_env("DOPF_QUIET_ANY_SIZE")) &&
                       !(q->flags & DOPF_F_NO_QUIET);
+        // the same chain on a peer exchange (k_slack stays: its node sums are what is exchanged): a function of the problem's shape and
+        // the flags only — every rank decides alike
+        c->comm_quiet_ok = v.slackDualOk && !(q->flags & (DOPF_F_KEEP_DELTAS | DOPF_F_NO_QUIET));
     }
     double *cons = nullptr;
     TRY(dev_alloc(c, &cons, NT + 2 * LT + 1));
@@ -624,7 +638,9 @@ int dopf_iterate(dopf_ctx *c, int32_t n_iters, int32_t *iters_done, int32_t *con
         int slice = std::min(left, kCheckEvery);
         left -= slice;
         // the quiet chain (networks, no line flagged at the last look: no k_slack launch) has graphs of its own, built when first used
-        bool quiet = c->quiet_ok && c->quiet && c->comm == nullptr;
+        // (on a peer exchange: the chain without k_reduce, see enqueue_iteration — every rank takes the same decision from the same
+        // replicated status word at the same iteration)
+        bool quiet = c->quiet && (c->comm == nullptr ? c->quiet_ok : (c->comm_quiet_ok && comm_xchg(c) != nullptr && !c->tail_xchg));
         if (quiet && !eager && !c->graphs_q_valid) {
             int rc = build_graph(c, 1, &c->graph1q, true);
             if (rc == DOPF_OK) rc = build_graph(c, kMid, &c->graphMq, true);
@@ -655,7 +671,7 @@ int dopf_iterate(dopf_ctx *c, int32_t n_iters, int32_t *iters_done, int32_t *con
             continue;
         }
         if (c->host_st.halt) break;
-        c->quiet = c->quiet_ok && c->host_st.walk_last == 0;
+        c->quiet = (c->comm == nullptr ? c->quiet_ok : c->comm_quiet_ok) && c->host_st.walk_last == 0;
     }
     c->last_call_ms = -1.0;
     if (timed && left == 0) {
@@ -1151,7 +1167,9 @@ int dopf_debug_stats(dopf_ctx *c, uint64_t *out3 /* 15 values */)
 int dopf_debug_quiet(dopf_ctx *c, int64_t *out3)
 {
     if (!c || !out3) return DOPF_E_INVALID;
-    out3[0] = c->quiet_ok ? 1 : 0; out3[1] = c->quiet ? 1 : 0; out3[2] = (int64_t)c->quiet_parked;
+    // (a context on a communicator: the chain without k_reduce on a peer exchange, DevView::slackGlobal)
+    out3[0] = (c->comm ? (c->comm_quiet_ok && comm_xchg(c) != nullptr && !c->tail_xchg) : c->quiet_ok) ? 1 : 0;
+    out3[1] = c->quiet ? 1 : 0; out3[2] = (int64_t)c->quiet_parked;
     return DOPF_OK;
 }
 

@@ -393,35 +393,67 @@ int dopf_xchg_init(dopf_ctx *c, int32_t world, int32_t rank, const void *handles
     // already passes — refused here instead.
     if (int rcs = read_status(c)) { xchg_undo(c, cs); return rcs; }
     const unsigned long long one = (unsigned long long)c->host_st.iters_total + 1ull;
-    for (int r = 0; r < world; ++r) {
-        const hipError_t e = hipMemcpy((char *)areas[r] + (size_t)rank * sizeof one, &one, sizeof one, hipMemcpyHostToDevice);
-        if (e != hipSuccess) { xchg_undo(c, cs); return fail(c, DOPF_E_DEVICE, "peer exchange: hello to rank %d: %s", r, hipGetErrorString(e)); }
-    }
+    constexpr unsigned long long kPhase2 = 1ull << 62;          // second rendezvous: the lines' reach has been handed round
     double wait_s = 120.0;
     if (const char *e = exp_env("DOPF_XCHG_HELLO_S")) wait_s = atof(e);
     const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        unsigned long long hello[kXchgMaxWorld];
-        {
+    auto say = [&](unsigned long long word) -> int {
+        for (int r = 0; r < world; ++r) {
+            const hipError_t e = hipMemcpy((char *)areas[r] + (size_t)rank * sizeof word, &word, sizeof word, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { xchg_undo(c, cs); return fail(c, DOPF_E_DEVICE, "peer exchange: hello to rank %d: %s", r, hipGetErrorString(e)); }
+        }
+        return DOPF_OK;
+    };
+    auto wait_all = [&](unsigned long long need_bits) -> int {      // every rank's word is there (and carries need_bits)
+        for (;;) {
+            unsigned long long hello[kXchgMaxWorld];
             const hipError_t e = hipMemcpy(hello, cs->xbuf, sizeof hello, hipMemcpyDeviceToHost);
             if (e != hipSuccess) { xchg_undo(c, cs); return fail(c, DOPF_E_DEVICE, "peer exchange: reading the hello words: %s", hipGetErrorString(e)); }
+            int seen = 0;
+            for (int r = 0; r < world; ++r) seen += hello[r] != 0ull && (hello[r] & need_bits) == need_bits;
+            if (seen == world) {
+                for (int r = 0; r < world; ++r)
+                    if ((hello[r] & ~kPhase2) != one) {
+                        xchg_undo(c, cs);
+                        return fail(c, DOPF_E_INVALID, "peer exchange: rank %d joins after %llu iterations, this rank after %llu — the ranks "
+                                    "must join with the same iteration count", r, (hello[r] & ~kPhase2) - 1ull, one - 1ull);
+                    }
+                return DOPF_OK;
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_s) {
+                xchg_undo(c, cs);
+                return fail(c, DOPF_E_DEVICE, "peer exchange: %d of %d ranks showed up within %.0f s", seen, world, wait_s);
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
         }
-        int seen = 0;
-        for (int r = 0; r < world; ++r) seen += hello[r] != 0ull;
-        if (seen == world) {
-            for (int r = 0; r < world; ++r)
-                if (hello[r] != one) {
-                    xchg_undo(c, cs);
-                    return fail(c, DOPF_E_INVALID, "peer exchange: rank %d joins after %llu iterations, this rank after %llu — the ranks "
-                                "must join with the same iteration count", r, hello[r] - 1ull, one - 1ull);
-                }
-            break;
+    };
+    if (int rc = say(one)) return rc;
+    if (int rc = wait_all(0ull)) return rc;
+    // Networks: which lines' slack sums need the agents one by one ("flagged") is decided from each line's REACH — the largest
+    // move any agent of any node can make, seen through the line — and a rank knows only its own agents. The ranks hand their
+    // reaches round (through the receive areas just mapped, before any iteration uses them) and keep the elementwise maximum:
+    // from here on the flags, and with them the choice between the chain with k_reduce and the one without
+    // (DevView::slackGlobal), are the same replicated state on every rank as the duals they are computed from.
+    if (c->v.L > 0) {
+        const XchgLayout lay((size_t)dopf_consensus_size(c), world);
+        const size_t L = (size_t)c->v.L;
+        for (int r = 0; r < world; ++r) {
+            const hipError_t e = hipMemcpy((char *)areas[r] + lay.data_off + (size_t)rank * lay.n * sizeof(double), c->v.line_reach,
+                                           L * sizeof(double), hipMemcpyDeviceToDevice);
+            if (e != hipSuccess) { xchg_undo(c, cs); return fail(c, DOPF_E_DEVICE, "peer exchange: reach to rank %d: %s", r, hipGetErrorString(e)); }
         }
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > wait_s) {
-            xchg_undo(c, cs);
-            return fail(c, DOPF_E_DEVICE, "peer exchange: %d of %d ranks showed up within %.0f s", seen, world, wait_s);
+        if (hipDeviceSynchronize() != hipSuccess) { xchg_undo(c, cs); return fail(c, DOPF_E_DEVICE, "peer exchange: reach hand-over did not complete"); }
+        if (int rc = say(one | kPhase2)) return rc;
+        if (int rc = wait_all(kPhase2)) return rc;
+        std::vector<double> mx(L, 0.0), got(L);
+        for (int r = 0; r < world; ++r) {
+            const hipError_t e = hipMemcpy(got.data(), (char *)cs->xbuf + lay.data_off + (size_t)r * lay.n * sizeof(double), L * sizeof(double), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { xchg_undo(c, cs); return fail(c, DOPF_E_DEVICE, "peer exchange: reading rank %d's reach: %s", r, hipGetErrorString(e)); }
+            for (size_t l = 0; l < L; ++l) mx[l] = std::max(mx[l], got[l]);
         }
-        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        const hipError_t e = hipMemcpy(const_cast<double *>(c->v.line_reach), mx.data(), L * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { xchg_undo(c, cs); return fail(c, DOPF_E_DEVICE, "peer exchange: storing the common reach: %s", hipGetErrorString(e)); }
+        // (the slots used here are overwritten by the first iteration's exchange; their flags were never set)
     }
     drop_graphs(c);
     return DOPF_OK;
@@ -559,6 +591,26 @@ int dopf_multi_create(dopf_multi **out, const dopf_problem *p, const dopf_params
             areas[i] = cs->xbuf;
         }
         for (int i = 0; i < n_gpus; ++i) xchg_fill_view(m->ctx[i], m->ctx[i]->comm, n_gpus, i, areas);
+        // the lines' common reach (see dopf_xchg_init: the flags it decides must be the same replicated state on every shard)
+        if (p->L > 0) {
+            const size_t L = (size_t)p->L;
+            std::vector<double> mx(L, 0.0), got(L);
+            bool ok = true;
+            for (int i = 0; i < n_gpus && ok; ++i) {
+                DeviceGuard guard(m->ctx[i]->device);
+                ok = hipMemcpy(got.data(), m->ctx[i]->v.line_reach, L * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+                for (size_t l = 0; l < L; ++l) mx[l] = std::max(mx[l], got[l]);
+            }
+            for (int i = 0; i < n_gpus && ok; ++i) {
+                DeviceGuard guard(m->ctx[i]->device);
+                ok = hipMemcpy(const_cast<double *>(m->ctx[i]->v.line_reach), mx.data(), L * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+            }
+            if (!ok) {
+                snprintf(g_multi_err, 512, "peer exchange: the lines' common reach could not be set");
+                dopf_multi_destroy(m);
+                return DOPF_E_DEVICE;
+            }
+        }
     } else if (n_gpus > 1 || host_sum) {
         std::vector<ncclComm_t> comms(n_gpus, nullptr);
         if (!host_sum) {

@@ -24,7 +24,8 @@ struct dopf_ctx {
     // k_net_agents and the dual/price kernel, which forms the node sums itself; k_slack is not launched. Graphs of its own.
     hipGraphExec_t graph1q = nullptr, graphMq = nullptr, graphUq = nullptr;
     bool graphs_q_valid = false;
-    bool quiet_ok = false;          // the problem, the flags and the environment allow the quiet chain
+    bool quiet_ok = false;          // the problem and the flags allow the quiet chain
+    bool comm_quiet_ok = false;     // ... and its form on a peer exchange (k_slack, exchange of the node sums, dual/price kernel: no k_reduce)
     bool quiet = false;             // the next launches may use it
     unsigned long long quiet_parked = 0;    // times the quiet chain parked itself (a line got flagged) and the host went back
     std::vector<void *> allocs;
@@ -44,8 +45,8 @@ namespace dopf {
 
 int fail(dopf_ctx *c, int code, const char *fmt, ...);
 void keep_error(const dopf_ctx *c);          // the context's message becomes what dopf_last_error(NULL) returns
-void enqueue_local(dopf_ctx *c, bool single, bool quiet = false);
-void enqueue_apply(dopf_ctx *c, bool single, const XchgView *xd = nullptr, bool quiet = false);
+void enqueue_local(dopf_ctx *c, bool single, bool quiet = false, bool comm_quiet = false);
+void enqueue_apply(dopf_ctx *c, bool single, const XchgView *xd = nullptr, bool quiet = false, bool comm_quiet = false);
 void drop_graphs(dopf_ctx *c);
 int read_status(dopf_ctx *c);
 // dopf_comm.hip

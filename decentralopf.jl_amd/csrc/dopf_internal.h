@@ -93,6 +93,10 @@ struct DevView {
                                     // sums and the cost itself, the dual/price block of timestep t forms the slack sums of its lines from the
                                     // PTDF rows it reads anyway — no k_reduce launch
     int slackDualOk;                // the problem and the flags allow that
+    int slackGlobal;                // per launch (contexts on a peer exchange, no line flagged): the chain of slackInDual with the exchange of
+                                    // the node sums between k_slack and the dual/price kernel — that kernel then takes the nodes' injection
+                                    // changes from the SUMMED injections (this iteration's minus the previous one's, both replicated) and counts
+                                    // all ranks' agents; a dual step that flags a line parks the chain (as the quiet chain does)
     int quiet;                      // per launch (with slackInDual): the quiet chain — no line is flagged, k_slack is not launched, the dual/price
                                     // kernel forms the node sums too
     int genTT256;                   // networks, fused launch: column tiling of a 256-thread generator block with the same R as genR
@@ -104,6 +108,7 @@ struct DevView {
     int keepDeltas;                 // DOPF_F_KEEP_DELTAS: dltG / dltS are written for every timestep (diagnostic getters)
     int rootCap;                    // iteration cap of the scan kernel's root search (80; 2 with DOPF_F_DEBUG_ROOT_CAP)
     double gamma, w_flow, w_prox, eps, mask_thr, invA;
+    double nAgents;                 // the divisor of avg_U / avg_K as a number: all ranks' agents (1 / invA without the rounding)
     double cp_ia, cp_idet, cp_s2;   // copper-plate box2 constants with a = w_prox + gamma, b = gamma: 1/a, 1/(a^2 - b^2), 2/(a + b) (host: no divisions per block)
     // problem (read-only)
     const double *demand, *ptdf, *fmax;
@@ -244,7 +249,8 @@ struct XchgView {
     double *sum[kXchgMaxWorld];                 // [2 parities][n]: the summed chunks, written by each chunk's owner (rs form)
     unsigned long long *sflags[kXchgMaxWorld];  // [2][chunks]
 };
-void launch_xchg(const DevView &v, const XchgView &x, hipStream_t s);   // cons <- sum over ranks of cons (rank order)
+void launch_xchg(const DevView &v, const XchgView &x, hipStream_t s, bool inj_only = false);   // cons <- sum over ranks of cons (rank order);
+//      // inj_only: just the chunks that hold the node sums and the cost (the slack sums are formed behind the exchange: slackGlobal)
 void launch_dual(const DevView &v, hipStream_t s, const XchgView *xd = nullptr);   // xd: peer exchange inside the one-block kernel
 //      // consensus -> duals, residuals, prices, status
 void launch_derive(const DevView &v, hipStream_t s, bool from_primal);

@@ -646,11 +646,14 @@ void launch_reduce(const DevView &v, hipStream_t s)
 // Latency: one kernel, one xGMI store + one flag round trip (a few microseconds) against the 20-30 us of a library
 // all-reduce for the sub-kilobyte vector of a copper plate (776 B on config2).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_xchg(DevView v, XchgView x)
+// (sub > 0: only the first sub - 1 chunks and the vector's last chunk are exchanged — the node sums and the cost; a chunk's flags
+// and slots are its own, so chunks that sit an iteration out just keep their older sequence numbers)
+__global__ __launch_bounds__(256) void k_xchg(DevView v, XchgView x, int sub)
 {
     if (v.st->halt) return;
     __shared__ int bad;
-    const int tid = threadIdx.x, W = x.world, me = x.me, chunk = blockIdx.x;
+    const int tid = threadIdx.x, W = x.world, me = x.me;
+    const int chunk = (sub > 0 && (int)blockIdx.x == sub - 1) ? x.nchunks - 1 : (int)blockIdx.x;
     const unsigned long long seq = (unsigned long long)v.st->iters_total + 1ull;
     const size_t par = (size_t)(seq & 1ull), n = x.n, j0 = (size_t)chunk * kXchgChunk;
     constexpr int U = kXchgChunk / 256;
@@ -713,11 +716,12 @@ __global__ __launch_bounds__(256) void k_xchg(DevView v, XchgView x)
 // the replicated state stays bitwise identical. A block sends before it waits, an owner waits only for sends, the
 // others only for the owner: no cycle, whatever the order blocks run in. Two parities suffice as before (a rank sends
 // k+2 only after it has consumed the sum of k+1, which exists only after everybody's k+1 has been consumed).
-__global__ __launch_bounds__(256) void k_xchg_rs(DevView v, XchgView x)
+__global__ __launch_bounds__(256) void k_xchg_rs(DevView v, XchgView x, int sub)
 {
     if (v.st->halt) return;
     __shared__ int bad;
-    const int tid = threadIdx.x, W = x.world, me = x.me, chunk = blockIdx.x, owner = chunk % W;
+    const int tid = threadIdx.x, W = x.world, me = x.me;
+    const int chunk = (sub > 0 && (int)blockIdx.x == sub - 1) ? x.nchunks - 1 : (int)blockIdx.x, owner = chunk % W;
     const unsigned long long seq = (unsigned long long)v.st->iters_total + 1ull;
     const size_t par = (size_t)(seq & 1ull), n = x.n, j0 = (size_t)chunk * kXchgChunk;
     constexpr int U = kXchgChunk / 256;
@@ -799,10 +803,15 @@ __global__ __launch_bounds__(256) void k_xchg_rs(DevView v, XchgView x)
     }
 }
 
-void launch_xchg(const DevView &v, const XchgView &x, hipStream_t s)
+void launch_xchg(const DevView &v, const XchgView &x, hipStream_t s, bool inj_only)
 {
-    if (x.rs) hipLaunchKernelGGL(k_xchg_rs, dim3(x.nchunks), dim3(256), 0, s, v, x);
-    else hipLaunchKernelGGL(k_xchg, dim3(x.nchunks), dim3(256), 0, s, v, x);
+    int sub = 0, grid = x.nchunks;
+    if (inj_only) {                      // the chunks of the node sums [0, N T) and the chunk of the cost (the vector's last entry)
+        const int ninj = (int)(((size_t)v.N * v.T + kXchgChunk - 1) / kXchgChunk);
+        if (ninj < x.nchunks) { sub = ninj + 1; grid = sub; }
+    }
+    if (x.rs) hipLaunchKernelGGL(k_xchg_rs, dim3(grid), dim3(256), 0, s, v, x, sub);
+    else hipLaunchKernelGGL(k_xchg, dim3(grid), dim3(256), 0, s, v, x, sub);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1176,8 +1185,10 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         f_old = v.flow[i]; aU_old = v.avgU[i]; aK_old = v.avgK[i]; F = v.fmax[l];
     }
     if (mine) {
-        wf = QUIET ? 0 : v.walk_flag[i];
+        wf = (QUIET || v.slackGlobal) ? 0 : v.walk_flag[i];       // (slackGlobal: the host runs this chain only while no line is flagged)
         cntp = (double)((v.node_gen_beg[nend] - v.node_gen_beg[nbeg]) + (v.node_sto_beg[nend] - v.node_sto_beg[nbeg]));   // agents at the part's nodes
+        // behind an exchange the nodes' changes are all ranks': so is the count (the parts' counts only ever meet as their sum)
+        if (v.slackGlobal) cntp = pl == 0 ? v.nAgents : 0.0;
     }
     const double lam_old = v.lam[t], s_old = v.s[t];
     double x = 0.0, cost_q = 0.0;
@@ -1233,7 +1244,9 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
     } else if (tid < N) {
         x = cinj[tid + (size_t)N * t] - v.demand[tid + (size_t)N * t];       // results.jl:58-100
         q[tid] = x;
-        if (sid) sdL[tid] = v.node_dsum[tid + (size_t)N * t];
+        // the node's injection change of this iteration: k_slack's (this rank's agents), or — behind an exchange — the summed
+        // injection against the previous iteration's (replicated; v.inj is overwritten further down)
+        if (sid) sdL[tid] = v.slackGlobal ? x - v.inj[tid + (size_t)N * t] : v.node_dsum[tid + (size_t)N * t];
     }
     {   // imbalance: butterfly inside each of the (at most four) waves that hold nodes, waves in order
         double ps = x;
@@ -1475,7 +1488,7 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
             const int walks = (int)(tk_ >> 48) + (anyNeed ? 1 : 0);
             st->walk_last = walks;
             const int stop = conv || (v.max_iters > 0 && it > v.max_iters);
-            st->halt = stop ? 1 : ((QUIET && walks > 0) ? 2 : 0);
+            st->halt = stop ? 1 : (((QUIET || v.slackGlobal) && walks > 0) ? 2 : 0);
         }
     }
 }

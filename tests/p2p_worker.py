@@ -1,5 +1,6 @@
 """Started by tests/test_gpu_multi.py (GPU_MAX_HW_QUEUES=8, nothing else alive in the process): the peer exchange of
 dopf_multi_* with several shards on ONE device. See the test's docstring."""
+import ctypes as C
 import gc
 import os
 import sys
@@ -25,7 +26,13 @@ CASES = {
 KEYS = ("lam", "mu", "rho", "inj", "avg_U", "avg_K", "flow", "cost")
 
 
-def compare(pp, n, steps, kw, tol, xflags=0):
+def quiet_state(engine):
+    q = (C.c_int64 * 3)()
+    assert hip.lib.dopf_debug_quiet(engine._ctx, q) == 0
+    return int(q[0]), int(q[1]), int(q[2])          # the chain without k_slack / k_reduce: allowed, in use for the next call, times parked
+
+
+def compare(pp, n, steps, kw, tol, xflags=0, quiet_seen=None):
     ref = make_engine(hip, pp, **kw)
     wants = []
     for k in steps:
@@ -46,6 +53,10 @@ def compare(pp, n, steps, kw, tol, xflags=0):
                 if want[key].size:
                     assert np.abs(got[key] - want[key]).max() <= tol * max(1.0, np.abs(want[key]).max()), (key, i, k)
                     assert np.array_equal(got[key], first[key]), (key, i)        # rank-order sums: bitwise the same
+        if quiet_seen is not None:
+            qs = [quiet_state(m.shard(i)) for i in range(n)]
+            assert all(q == qs[0] for q in qs), qs                               # every shard takes the same decision
+            quiet_seen.append(qs[0])
     m.close()
     gc.collect()
 
@@ -86,6 +97,25 @@ A4 = pp4.G + pp4.S
 assert (pp4.N * pp4.T + 2 * pp4.L * pp4.T + 1 + 2047) // 2048 > 3
 compare(pp4, 3, (1, 5, 15), dict(eps=0.0, gamma=1.0 / A4, w_flow=0.3 / A4), 1e-8)
 print("reduce-scatter ok", flush=True)
+
+# Networks whose dual step is the one-launch kernel (here 118 nodes / 186 lines, 2 % of configs[3]'s agents): while no line is
+# flagged a shard's chain on the exchange is k_net_agents, k_slack, the exchange of the NODE SUMS, the dual/price kernel — which
+# forms the slack sums behind the exchange from the summed injections' changes (no k_reduce launch; DevView::slackGlobal). A
+# dual step that flags a line parks the chain on every shard alike and the host goes back to the chain with k_reduce.
+ppq = synth.baseline_config(3, scale=0.02)
+Aq = ppq.G + ppq.S
+for n, xf in ((2, 0), (3, 0), (3, _capi.F_XCHG_ALLGATHER)):
+    seen = []
+    # (on this small share lines get flagged again now and then: no flag after iterations 22-28, 45-54 and 166-196 — the calls end
+    # inside those windows, so the next call starts on the chain without k_reduce and is parked by the first new flag)
+    compare(ppq, n, (1, 4, 19, 26, 130, 40), dict(eps=0.0, gamma=1.0 / Aq, w_flow=0.3 / Aq), 1e-9, xflags=xf, quiet_seen=seen)
+    assert all(s[0] == 1 for s in seen) and [s[1] for s in seen] == [0, 0, 1, 1, 1, 0] and seen[-1][2] >= 2, seen     # allowed, ran, was parked
+    print("network chain without k_reduce on the exchange", n, "shards: in use after calls", [s[1] for s in seen], "parked", seen[-1][2], flush=True)
+# (DOPF_F_NO_QUIET keeps a context on the chain with k_reduce)
+seen = []
+compare(ppq, 2, (1, 4, 60), dict(eps=0.0, gamma=1.0 / Aq, w_flow=0.3 / Aq), 1e-9, xflags=_capi.F_NO_QUIET, quiet_seen=seen)
+assert all(s[0] == 0 and s[1] == 0 for s in seen), seen
+print("comm-quiet ok", flush=True)
 
 # the reference's shipped case: stops like check_convergence! on both shards
 nodes, lines, gens, stos = network.three_node_case()

@@ -232,7 +232,7 @@ def test_peer_exchange_shards_on_one_device(hip_api):
     r = subprocess.run([sys.executable, worker], env=dict(os.environ, GPU_MAX_HW_QUEUES="8", DOPF_XCHG_TIMEOUT_MS="4000"),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "p2p worker: ok" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
-    for line in ("equal network 2", "equal network 3", "equal copper plate 3", "equal copper plate T96 2", "three-launch exchange ok", "chunks ok", "reduce-scatter ok", "stop ok", "missing peer ok"):
+    for line in ("equal network 2", "equal network 3", "equal copper plate 3", "equal copper plate T96 2", "three-launch exchange ok", "chunks ok", "reduce-scatter ok", "comm-quiet ok", "stop ok", "missing peer ok"):
         assert line in r.stdout, (line, r.stdout[-1500:])
 
 

@@ -390,26 +390,52 @@ def test_hip_tail_in_the_launch_matches_the_three_launch_chain(hip_api, name, ma
 def test_hip_fixed_point_sums_at_the_admission_edge(hip_api, scale):
     """The one-launch iteration adds the blocks' sums as fixed-point integers whose binary point comes from the problem's
     bounds (k = 52 - ceil(log2(sum pmax)) fraction bits; dopf_create admits the tail only while k >= 8). Units scaled so that
-    k lands near that edge — 2^-19 ... 2^-8 MW per contribution and beyond: either the tail is in the launch and the iterates
-    follow the fp64 chain (DOPF_F_NO_TAIL_FUSE) to 1e-9 of their size, or the library has put the case on the fp64 chain."""
+    k sits on that edge and on both sides of it (12, 9, 8 | 7, 4): either the tail is in the launch, and then
+      * the consensus sum it forms is the EXACT sum of the agents' injections (math.fsum of the primal arrays the same context
+        returns) to within the resolution it promises — half a unit of 2^-k per contributing block (< 800 blocks) — while the
+        fp64 chain (DOPF_F_NO_TAIL_FUSE) is within the rounding of its own additions;
+      * the two chains' iterates agree to 1e-9 of the quantities being summed (sum pmax). (At these magnitudes the imbalance is
+        the difference of 13-digit numbers and the dual step multiplies what is left by gamma: neither chain can hold lambda
+        to 1e-9 of ITS size: they agree to 1e-7 ... 1e-4 of it here — asserted at 1e-3, a sanity bound; the statement about the
+        fixed-point sums is the first one);
+    or (k < 8) the library has put the case on the fp64 chain by itself."""
+    import math
     pp = synth.synthetic_case(300, 30, 24, seed=77)
     for arr in (pp.gen_pmax, pp.sto_pmax, pp.sto_emax, pp.demand):
         arr *= scale
-    k = 52 - int(np.ceil(np.log2(1.0 + pp.gen_pmax.sum() + pp.sto_pmax.sum())))
+    for arr in (pp.gen_mc, pp.sto_mc):       # (cheap units: the cost accumulator — |cost| <= T sum |mc| pmax in 53 bits — must not be
+        arr *= 2.0 ** -6                     # what keeps the tail out before the injection sums' binary point reaches the edge)
+    total = float(pp.gen_pmax.sum() + pp.sto_pmax.sum())
+    k = 52 - int(np.ceil(np.log2(1.0 + total)))
+    kc = 52 - int(np.ceil(np.log2(1.0 + pp.T * float((np.abs(pp.gen_mc) * pp.gen_pmax).sum() + (np.abs(pp.sto_mc) * 2.0 * pp.sto_pmax).sum()))))
+    assert {2.0 ** 24: 12, 2.0 ** 27: 9, 2.0 ** 28: 8, 2.0 ** 29: 7, 2.0 ** 32: 4}[scale] == k and (kc >= 0 or k < 8)
     g = 1.0 / (pp.G + pp.S)
     a = make_engine(hip_api, pp, eps=0.0, gamma=g)
     b = make_engine(hip_api, pp, eps=0.0, gamma=g, flags=_capi.F_NO_TAIL_FUSE)
     fused = a.iterate_timed(1)["tail_fused"]
     b.iterate(1)
     assert fused == (1 if k >= 8 else 0), (k, fused)
-    assert {2.0 ** 24: 12, 2.0 ** 27: 9, 2.0 ** 28: 8, 2.0 ** 29: 7, 2.0 ** 32: 4}[scale] == k       # the sweep sits on the edge (k = 8) and on both sides
+    ulp = float(np.spacing(total))
+
+    def exact_gap(e):           # |consensus injection - exact sum of the agents' injections|, worst timestep
+        P, D, C, _ = e.get_primal()
+        inj = e.get_consensus()[0]
+        want = [math.fsum(P[:, t]) + math.fsum(D[:, t]) - math.fsum(C[:, t]) - float(pp.demand[:, t].sum()) for t in range(pp.T)]
+        return float(np.abs(inj.sum(axis=0) - np.asarray(want)).max())
     for n in (1, 6, 40):
         a.iterate(n)
         b.iterate(n)
+        assert exact_gap(b) <= (pp.G + pp.S) * ulp, (k, n, exact_gap(b))
+        assert exact_gap(a) <= ((800 * 2.0 ** -(k + 1) + 2 * ulp) if fused else (pp.G + pp.S) * ulp), (k, n, exact_gap(a))
         sa, sb = state_of(a), state_of(b)
         for key in sa:
-            if sa[key].size:
-                assert np.abs(sa[key] - sb[key]).max() <= 1e-9 * (1.0 + np.abs(sb[key]).max()), (k, n, key)
+            if sa[key].size == 0:
+                continue
+            d = float(np.abs(sa[key] - sb[key]).max())
+            if key in ("lam",):
+                assert d <= 1e-3 * (1.0 + np.abs(sb[key]).max()), (k, n, key, d)
+            else:
+                assert d <= 1e-9 * total, (k, n, key, d)
     assert a.solver_failures() == 0 and b.solver_failures() == 0
 
 
