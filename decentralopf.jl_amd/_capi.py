@@ -47,7 +47,7 @@ class DopfTiming(C.Structure):
                 ("slack_ms", C.c_double), ("reduce_ms", C.c_double), ("dual_ms", C.c_double),
                 ("iter_ms", C.c_double), ("empty_ms", C.c_double), ("iters", C.c_int32),
                 ("agents_fused", C.c_int32), ("tail_fused", C.c_int32),
-                ("slack_in_dual", C.c_int32), ("quiet", C.c_int32)]
+                ("slack_in_dual", C.c_int32), ("quiet", C.c_int32), ("sto_lean", C.c_int32), ("persist", C.c_int32)]
 
 
 class DopfCentralResult(C.Structure):
@@ -74,6 +74,7 @@ F_XCHG_OWNER = 65536
 F_XCHG_ALLGATHER = 131072
 F_NO_TAIL_XCHG = 262144
 F_NET_SMALL_ITEMS = 524288
+F_PERSIST = 1048576
 COMM_ID_BYTES = 128
 XCHG_HANDLE_BYTES = 64
 

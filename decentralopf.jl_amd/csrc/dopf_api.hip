@@ -223,6 +223,17 @@ int enqueue_iteration(dopf_ctx *c, bool quiet = false)
     return DOPF_OK;
 }
 
+// several iterations in one launch (agents_persist.h): the single-GPU one-launch copper-plate chain only
+bool persist_on(const dopf_ctx *c) { return c->v.persistOk && c->comm == nullptr && c->v.tailDev != nullptr; }
+
+void enqueue_persist(dopf_ctx *c, int iters)
+{
+    DevView v = c->v;
+    v.tail = v.tailDev;
+    v.persistIters = iters;
+    launch_agents_persist(v, c->lc, c->main);
+}
+
 int build_graph(dopf_ctx *c, int iters, hipGraphExec_t *out, bool quiet = false)
 {
     hipGraph_t g = nullptr;
@@ -230,7 +241,8 @@ int build_graph(dopf_ctx *c, int iters, hipGraphExec_t *out, bool quiet = false)
     // from tripping over what other host threads — other GPUs' drivers — do meanwhile)
     HIPCHK(c, hipStreamBeginCapture(c->main, c->comm ? hipStreamCaptureModeThreadLocal : hipStreamCaptureModeRelaxed));
     int rc = DOPF_OK;
-    for (int i = 0; i < iters && rc == DOPF_OK; ++i) rc = enqueue_iteration(c, quiet);
+    if (persist_on(c)) enqueue_persist(c, iters);
+    else for (int i = 0; i < iters && rc == DOPF_OK; ++i) rc = enqueue_iteration(c, quiet);
     const hipError_t ec = hipStreamEndCapture(c->main, &g);
     if (rc) { if (g) hipGraphDestroy(g); return rc; }
     if (ec != hipSuccess) return fail(c, DOPF_E_DEVICE, "hipStreamEndCapture: %s", hipGetErrorString(ec));
@@ -446,6 +458,14 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         v.genBlocks = std::min(v.nGenItems, std::max(nb, 192));
     }
     v.genRows = v.genBlocks;
+    {   // several iterations per launch: every block of the fused launch must be resident at once — 3 blocks of 256 threads per CU at
+        // the kernel's register count, as many CUs as this device has (a grid that does not fit would time out, not hang)
+        hipDeviceProp_t prop{};
+        const bool known = hipGetDeviceProperties(&prop, c->device) == hipSuccess;
+        const bool full = T == lc.stoLPS * lc.stoNCH && lc.stoLPS <= 32;
+        v.persistOk = ((q->flags & DOPF_F_PERSIST) && tail_ok && v.fuseAgents && v.genBlocks > 0 && !v.genSkip && v.stoLean && full && S > 0 &&
+                       known && v.nStoItems + v.genBlocks + 1 <= 3 * prop.multiProcessorCount) ? 1 : 0;
+    }
     {
         // level-1 reduce blocks per node: ~16 items per block, at most 64 (and N*RB blocks in total)
         int max_items = 1;
@@ -649,7 +669,9 @@ int dopf_iterate(dopf_ctx *c, int32_t n_iters, int32_t *iters_done, int32_t *con
             c->graphs_q_valid = true;
         }
         const int asked = slice, total_before = c->host_st.iters_total;
-        if (eager) {
+        if (eager && persist_on(c)) {
+            for (; slice > 0; slice -= std::min(slice, kUnroll)) enqueue_persist(c, std::min(slice, kUnroll));
+        } else if (eager) {
             for (int i = 0; i < slice; ++i) { const int rc = enqueue_iteration(c, quiet); if (rc) return rc; }
         } else {
             for (; slice >= kUnroll; slice -= kUnroll) HIPCHK(c, hipGraphLaunch(quiet ? c->graphUq : c->graphU, c->main));
@@ -764,6 +786,8 @@ int dopf_iterate_timed(dopf_ctx *c, int32_t n_iters, dopf_timing *out)
     out->tail_fused = v.tail ? 1 : 0;
     out->slack_in_dual = (!v.tail && v.slackInDual) ? 1 : 0;
     out->quiet = v.quiet ? 1 : 0;
+    out->sto_lean = (v.stoLean && v.L == 0 && v.S > 0 && v.T == c->lc.stoLPS * c->lc.stoNCH && c->lc.stoLPS <= 32 && v.use_warm) ? 1 : 0;
+    out->persist = persist_on(c) ? 1 : 0;
     return DOPF_OK;
 }
 

@@ -56,6 +56,7 @@ struct Status {
     int xchg_timeout;       // peer exchange: a peer's part of the consensus sum did not arrive in time (sticky)
     int tail_timeout;       // tail in the launch: the block sums of an iteration did not all arrive in time (sticky)
     int tail_par;           // tail in the launch: which of the two accumulator sets the next launch adds into
+    int pseq;               // persistent iterations (agents_persist.h): dual updates published inside launches so far (wraps; only differences count)
 };
 
 struct XchgView;
@@ -104,6 +105,8 @@ struct DevView {
     int fuseAgents;                 // copper plate, even T: generators + storages in one launch (k_agents, 256-thread blocks)
     int use_warm;                   // storage warm-start kernel runs first; the scan kernel serves its failures
     int stoLean;                    // copper plates whose horizon fills the lane groups: the lean active-set body (sto_lean.h)
+    int persistOk;                  // DOPF_F_PERSIST and a grid whose blocks are all resident at once: several iterations per launch (agents_persist.h)
+    int persistIters;               // per launch: iterations this launch runs
     int max_iters;
     int keepDeltas;                 // DOPF_F_KEEP_DELTAS: dltG / dltS are written for every timestep (diagnostic getters)
     int rootCap;                    // iteration cap of the scan kernel's root search (80; 2 with DOPF_F_DEBUG_ROOT_CAP)
@@ -228,6 +231,7 @@ void launch_gen_update(const DevView &v, hipStream_t s);
 void launch_sto_update(const DevView &v, const Launch &lc, hipStream_t s);
 void launch_net_agents(const DevView &v, const Launch &lc, hipStream_t s);
 void launch_agents_fused(const DevView &v, const Launch &lc, hipStream_t s);
+void launch_agents_persist(const DevView &v, const Launch &lc, hipStream_t s);        // v.persistIters iterations in one launch
 bool sto_config_supported(int T, Launch *lc);
 int debug_timeline(unsigned long long *out, int n);     // DOPF_STATS builds: per-wave stamps of the storage body
 // kernels_consensus.hip

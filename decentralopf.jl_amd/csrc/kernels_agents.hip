@@ -49,6 +49,13 @@ __device__ __forceinline__ double rcp64(double x)
     return r;
 }
 
+// Loads / stores of words that ANOTHER block of the SAME launch wrote or will read (the persistent iterations of
+// agents_persist.h): agent scope — past the CU's vector L1 and the scalar cache, which are only refreshed between launches.
+__device__ __forceinline__ double p_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int p_ldi(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void p_st(double *p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void p_sti(int *p, int x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // ------------------------------------------------------------------------------------------------
 // the tail of the iteration inside the x-update launch (DevView::tail; one node, no lines)
 // ------------------------------------------------------------------------------------------------
@@ -488,14 +495,14 @@ __global__ __launch_bounds__(512) void k_gen_update(DevView v)
 // LDS_ONLY: the barrier waits for this wave's LDS traffic only. __syncthreads() also drains every global load in
 // flight (s_waitcnt vmcnt(0)) — in the streaming blocks those are the NEXT item's rows, i.e. exactly the overlap the
 // streaming is for. Only LDS data crosses this barrier.
-template <int BS, bool TAIL, bool LDS_ONLY = false>
+template <int BS, bool TAIL, bool LDS_ONLY = false, bool PERSIST = false>
 __device__ __forceinline__ void gen_pair_sums(const DevView &v, const int blk, const int tid, const int r, const int tt,
-                                              double acc0, double acc1, double cost, double (*red)[BS], double *wc)
+                                              double acc0, double acc1, double cost, double (*red)[BS], double *wc, const int ppar = 0)
 {
     const int T = v.T, TT = v.genTT2, R = v.genR2;
     TailView tv{};                                           // TAIL: the launch chain carries the iteration's tail
     int par = 0;
-    if (TAIL) { tv = *v.tail; par = v.st->tail_par; }        // (uniform scalar loads, in flight with the LDS traffic below)
+    if (TAIL) { tv = *v.tail; par = PERSIST ? ppar : v.st->tail_par; }        // (uniform scalar loads, in flight with the LDS traffic below)
     for (int d = 32; d > 0; d >>= 1) cost += __shfl_xor(cost, d);
     red[0][tid] = acc0; red[1][tid] = acc1;
     if ((tid & 63) == 0) wc[tid >> 6] = cost;
@@ -1010,8 +1017,8 @@ struct StoAgent {
 // `item_fail`: number of storages of this item the warm start left over (block-uniform); < 0 = read it
 // FULLT: the horizon fills the lane group exactly (T == LPS * NCH: 24 = 8 x 3, 48 = 16 x 3, 96 = 32 x 3): T is then a
 // compile-time constant and every "is this step inside the horizon" test folds away
-template <int LPS, int NCH, bool LINES, bool TAIL = false, bool FULLT = false>
-__device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, int item_fail)
+template <int LPS, int NCH, bool LINES, bool TAIL = false, bool FULLT = false, bool PERSIST = false>
+__device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, int item_fail, const int ppar = 0)
 {
     constexpr int NG = 256 / LPS;
     __shared__ double red[NG * LPS * NCH];
@@ -1037,7 +1044,7 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
     for (int c = 0; c < NCH; ++c) {
         const int t = tbase + c;
         accQ[c] = 0.0;
-        th0[c] = (!LINES && t < T) ? v.price[it.node + N * t] + gam * v.s[t] : 0.0;
+        th0[c] = (!LINES && t < T) ? (PERSIST ? p_ld(v.price + it.node + N * t) + gam * p_ld(v.s + t) : v.price[it.node + N * t] + gam * v.s[t]) : 0.0;
     }
     // with lines: a (node, timestep) whose table is empty — no kink of Psi inside the node's window, the usual case —
     // is the copper-plate closed form with (Psi(0), slope) in place of (theta, gamma): cached here, no table reads
@@ -1321,7 +1328,7 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
                 double sum = 0.0;
                 for (int g2 = 0; g2 < NG; ++g2) sum += red[(g2 * LPS + li) * NCH + c];
                 // (tail in the launch: this thread wrote the active-set body's sum of slot t itself, a moment ago)
-                if (TAIL) { const TailView tv = *v.tail; acc_add(tv, v.st->tail_par, t, sum + v.part_sinj_w[(size_t)blk * T + t], tv.scaleInj); }
+                if (TAIL) { const TailView tv = *v.tail; acc_add(tv, PERSIST ? ppar : v.st->tail_par, t, sum + v.part_sinj_w[(size_t)blk * T + t], tv.scaleInj); }
                 else v.part_sinj[(size_t)blk * T + t] = sum;
             }
         }
@@ -1331,7 +1338,7 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
         __syncthreads();
     }
     if (tid == 0) {
-        if (TAIL) { const TailView tv = *v.tail; acc_add(tv, v.st->tail_par, T, redc[0] + v.part_scost_w[blk], tv.scaleCost); }
+        if (TAIL) { const TailView tv = *v.tail; acc_add(tv, PERSIST ? ppar : v.st->tail_par, T, redc[0] + v.part_scost_w[blk], tv.scaleCost); }
         else v.part_scost[blk] = redc[0];
     }
     if (fails) atomicAdd(&v.st->solver_fail, fails);
@@ -2236,8 +2243,11 @@ __global__ __launch_bounds__(256, 3) void k_agents(DevView v)
 }
 
 // The same two launches with the lean copper-plate storage body (sto_lean.h): horizon == LPS * NCH, at most 32 lanes per storage.
+#ifndef DOPF_LEAN_STO_WAVES
+#define DOPF_LEAN_STO_WAVES 3
+#endif
 template <int LPS, int NCH, bool TAIL>
-__global__ __launch_bounds__(256, 3) void k_sto_l(DevView v)
+__global__ __launch_bounds__(256, DOPF_LEAN_STO_WAVES) void k_sto_l(DevView v)
 {
     if (TAIL && (int)blockIdx.x == v.nStoItems) { tail_block(v.self); return; }
     const int left = sto_lean_body<LPS, NCH, TAIL>(v, blockIdx.x, v.st->halt);
@@ -2271,6 +2281,10 @@ __global__ __launch_bounds__(256, 3) void k_agents_l(DevView v)
     if (threadIdx.x == 0 && blockIdx.x < 8192 * 4) g_timeline[32768 + 2 * blockIdx.x + 1] = wall_clock64();
 #endif
 }
+
+}  // namespace dopf
+#include "agents_persist.h"
+namespace dopf {
 
 int debug_timeline(unsigned long long *out, int n)
 {
@@ -2362,6 +2376,16 @@ void launch_agents_fused(const DevView &v, const Launch &lc, hipStream_t s)
     DOPF_CASE(16, 3)
     DOPF_CASE(32, 3)
     DOPF_CASE(64, 3)
+#undef DOPF_CASE
+}
+
+void launch_agents_persist(const DevView &v, const Launch &lc, hipStream_t s)
+{
+    const dim3 grid(v.nStoItems + v.genBlocks + 1);
+#define DOPF_CASE(LPS_, NCH_) if (lc.stoLPS == LPS_ && lc.stoNCH == NCH_) { hipLaunchKernelGGL((k_agents_p<LPS_, NCH_>), grid, dim3(256), 0, s, v); return; }
+    DOPF_CASE(8, 1) DOPF_CASE(8, 2) DOPF_CASE(8, 3)
+    DOPF_CASE(16, 3)
+    DOPF_CASE(32, 3)
 #undef DOPF_CASE
 }
 

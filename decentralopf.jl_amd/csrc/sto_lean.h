@@ -158,9 +158,27 @@ __device__ __forceinline__ void lz_seg_maxmin(double K, double &a, double &b)
 #undef DOPF_LZ_STEP
 }
 
+// persistent iterations (agents_persist.h): Status::pseq = number of dual updates published inside launches (low 30 bits) | the halt
+// word of the last of them (bit 31). One lane waits until the count has reached `want`; returns the word, or all ones on a time-out.
+constexpr unsigned kPersistHaltBit = 0x80000000u, kPersistSeqMask = 0x3fffffffu;
+__device__ __forceinline__ unsigned persist_wait_word(Status *st, const unsigned want)
+{
+    const unsigned long long t0 = wall_clock64();
+    for (unsigned round = 1;; ++round) {
+        const unsigned w = (unsigned)p_ldi(reinterpret_cast<const int *>(&st->pseq));
+        if (((w - want) & kPersistSeqMask) < 0x20000000u) return w;          // (count >= want, wrap-safe)
+        if ((round & 255u) == 0u && wall_clock64() - t0 > 200000000ull) return 0xffffffffu;      // 2 s of the 100 MHz wall clock
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 // returns the number of storages of the item left to the scan body (block-uniform); -1 = halted
-template <int LPS, int NCH, bool TAIL>
-__device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, const int halt)
+// PERSIST (agents_persist.h: several iterations in one launch): the prices another block of this launch has just published are
+// read past the caches, and the accumulator set is the caller's (`ppar`), not the status block's word.
+// (PERSIST, pwant != 0: the wait for the previous iteration's prices happens INSIDE, behind the first pass's row loads — those
+// do not depend on the prices; returns -1 when the wait found the halted state or timed out: nothing stored)
+template <int LPS, int NCH, bool TAIL, bool PERSIST = false>
+__device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, const int halt, const int ppar = 0, const unsigned pwant = 0u)
 {
     static_assert(LPS <= 32 && NCH <= 8, "the row_bcast steps assume at most two rows per group; 4 pattern bits per step");
     constexpr int NG = 256 / LPS, T = LPS * NCH;
@@ -190,11 +208,14 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
     // step and pass) instead of registers (the kernel sits at its register limit) or two more loads per step and pass, whose
     // addresses cost a v_readlane each once the solve has taken the scalar registers.
     __shared__ double th0L[T];
-    if (tid < LPS) {
+    __shared__ int goL;
+    if (!PERSIST) {
+        if (tid < LPS) {
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) th0L[tbase + c] = v.price[it.node + N * (tbase + c)] + gam * v.s[tbase + c];
+            for (int c = 0; c < NCH; ++c) th0L[tbase + c] = v.price[it.node + N * (tbase + c)] + gam * v.s[tbase + c];
+        }
+        __syncthreads();
     }
-    __syncthreads();
 #ifdef DOPF_STATS
     unsigned long long st_rounds = 0, st_newton = 0, st_short = 0;
 #endif
@@ -215,12 +236,39 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
         const bool havenu = live && pv->nu_valid[s] != 0;
         double A0[NCH], B0[NCH], nuv[NCH], dq[NCH];      // rD = A0 - nu, rC = B0 + nu
         double run = 0.0;
+        double d0r[NCH], c0r[NCH], nur[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int t = tbase + c;
             const size_t e = (size_t)s * T + (live ? t : 0);
-            const double d0 = live ? pv->D[e] : 0.0, c0 = live ? pv->C[e] : 0.0;
-            const double nu_st = pv->nu_prev[live ? e : 0];      // (always loaded, from a valid address: sto_warm_body)
+            d0r[c] = live ? pv->D[e] : 0.0; c0r[c] = live ? pv->C[e] : 0.0;
+            nur[c] = pv->nu_prev[live ? e : 0];      // (always loaded, from a valid address: sto_warm_body)
+        }
+        if (PERSIST && rep == 0) {
+            // the rows above are on their way; now the prices the launch's tail block publishes (agents_persist.h)
+            if (tid == 0) {
+                int go = 1;
+                if (pwant != 0u) {
+                    const unsigned w = persist_wait_word(v.st, pwant);
+                    go = w == 0xffffffffu ? -1 : ((w & kPersistHaltBit) ? 0 : 1);
+                }
+                goL = go;
+            }
+            __syncthreads();
+            if (goL <= 0) {
+                if (goL < 0 && tid == 0) v.st->tail_timeout = 1;
+                return -1;
+            }
+            if (tid < LPS) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) th0L[tbase + c] = p_ld(v.price + it.node + N * (tbase + c)) + gam * p_ld(v.s + tbase + c);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int t = tbase + c;
+            const double d0 = d0r[c], c0 = c0r[c], nu_st = nur[c];
             const double th0 = th0L[t];
             const double theta = th0 - gam * (d0 - c0);
             dq[c] = c0 - d0;
@@ -656,7 +704,7 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
 #endif
     TailView tv{};
     int tpar = 0;
-    if (TAIL) { tv = *pf->tailDev; tpar = pf->st->tail_par; }   // (TAIL: this launch adds into the accumulators; uniform scalar loads,
+    if (TAIL) { tv = *pf->tailDev; tpar = PERSIST ? ppar : pf->st->tail_par; }   // (TAIL: this launch adds into the accumulators; uniform scalar loads,
                                                                 // in flight across the barrier. The per-launch fields of the view live in the kernel arguments only.)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const int blockFail = wfailS[0] + wfailS[1] + wfailS[2] + wfailS[3];

@@ -133,6 +133,9 @@ typedef struct dopf_params {
                                   * three-launch chain instead of inside the tail block of the one-launch iteration */
 #define DOPF_F_NET_SMALL_ITEMS 524288 /* networks, one launch for all agents: cut the generators into the ~1024 items the separate
                                   * launches use instead of ~512 larger ones (same partial-sum rows on both chains: bitwise comparisons) */
+#define DOPF_F_PERSIST 1048576 /* copper plates whose x-update is one launch with every block resident (config1, config2): run the
+                                  * iterations of a dopf_iterate call in launches of up to 16 ITERATIONS each — the grid stays, the tail block
+                                  * publishes the new prices to the other blocks (csrc/agents_persist.h; round 4 experiment) */
 /* Everything else that steers kernel selection is decided from the problem's shape ("which chain runs"). The
  * library reads two environment variables, neither of which changes results: DOPF_GUARD (debug allocator) and DOPF_XCHG_TIMEOUT_MS
  * (how long an exchange kernel waits for a lost peer). Tuning knobs of the experiments (item counts, block counts, launch splits)
@@ -240,6 +243,9 @@ typedef struct dopf_timing {
                                reduce_ms is an empty event pair */
     int32_t quiet;          /* 1 (networks): no line was flagged, k_slack was not launched (slack_ms is an empty event pair): the dual/price
                                kernel formed the node sums too */
+    int32_t sto_lean;       /* 1: the storages of this problem are solved by the lean copper-plate body (csrc/sto_lean.h) */
+    int32_t persist;        /* 1: dopf_iterate runs several iterations per launch on this context (DOPF_F_PERSIST; this timed call itself
+                               launches iteration by iteration) */
 } dopf_timing;
 int dopf_iterate_timed(dopf_ctx *ctx, int32_t n_iters, dopf_timing *out);
 /* DOPF_F_TIME_CALLS: milliseconds between the first launch of the last dopf_iterate call and the end of its last one, on the

@@ -439,6 +439,48 @@ def test_hip_fixed_point_sums_at_the_admission_edge(hip_api, scale):
     assert a.solver_failures() == 0 and b.solver_failures() == 0
 
 
+PERSIST = [
+    ("T24", lambda: synth.synthetic_case(1000, 100, 24, seed=20220720)),                 # config1's shape (8 lanes x 3 steps)
+    ("T96", lambda: synth.synthetic_case(6000, 600, 96, seed=3)),                        # config2's shape (32 x 3), several passes per block
+    ("T48 mixed storages", lambda: synth.synthetic_case(3000, 500, 48, seed=8)),
+]
+
+
+@pytest.mark.parametrize("name,make", PERSIST, ids=[t[0] for t in PERSIST])
+def test_hip_persistent_iterations_match_the_launch_per_iteration_chain(hip_api, name, make):
+    """DOPF_F_PERSIST (csrc/agents_persist.h): up to 16 iterations per launch — the grid stays, the tail block publishes the new
+    prices to the other blocks — against one launch per iteration: the same kernels' arithmetic in the same order, so every
+    array is bit-identical, after calls of any length (1, 4 and 16 iterations per launch, mixed), through the cold start (storage
+    blocks that hand storages to the scan body), and the stop test fires at the same iteration and freezes the state."""
+    pp = make()
+    if "mixed" in name:
+        rng = np.random.default_rng(5)
+        pp.sto_emax = pp.sto_pmax * rng.choice([0.7, 1.0, 2.0, 3.3], size=pp.S)
+    g = 1.0 / (pp.G + pp.S)
+    a = make_engine(hip_api, pp, eps=0.0, gamma=g, flags=_capi.F_PERSIST)
+    b = make_engine(hip_api, pp, eps=0.0, gamma=g)
+    ta, tb = a.iterate_timed(1), b.iterate_timed(1)
+    assert ta["persist"] == 1 and tb["persist"] == 0 and ta["tail_fused"] == 1 and ta["sto_lean"] == 1
+    for n in (1, 2, 5, 16, 37, 64, 3):
+        a.iterate(n)
+        b.iterate(n)
+        sa, sb = state_of(a), state_of(b)
+        for k in sa:
+            if sa[k].size:
+                assert np.array_equal(sa[k], sb[k]), (n, k, float(np.abs(sa[k] - sb[k]).max()))
+        assert a.get_residuals() == b.get_residuals()
+    assert a.solver_failures() == 0 and b.solver_failures() == 0
+    c = make_engine(hip_api, pp, gamma=g, flags=_capi.F_PERSIST, max_iters=5000)
+    d = make_engine(hip_api, pp, gamma=g, max_iters=5000)
+    rc, rd = c.iterate(5000), d.iterate(5000)
+    assert rc == rd and rc[1]
+    assert c.iterate(10) == (0, True)
+    sc, sd = state_of(c), state_of(d)
+    for k in sc:
+        if sc[k].size:
+            assert np.array_equal(sc[k], sd[k]), k
+
+
 SLACK_IN_DUAL = [
     ("30 nodes / 45 lines, limits binding", lambda: synth.synthetic_case(500, 50, 168, N=30, L=45, seed=11, fmax_factor=1.0, fmax_min=20), 0.3),
     ("30 nodes / 45 lines, literal flow weight", lambda: synth.synthetic_case(500, 50, 168, N=30, L=45, seed=12), None),
