@@ -442,6 +442,19 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         if (const char *e = exp_env("DOPF_STO_TARGET_ITEMS")) sto_target = std::max(1, atoi(e));     // (experiments)
         int schunk = std::max(NG, (S + sto_target - 1) / sto_target);
         schunk = (schunk + NG - 1) / NG * NG;
+        // Big copper plates (the storage solve is a launch of its own: config4): as many passes per block as make the launch ONE
+        // resident round — 3 blocks of 256 threads per CU at the storage code's register count — instead of several rounds of
+        // shorter blocks (the blocks' fixed cost — entry, constants, the block's sums — is paid per block, and a round's last
+        // blocks leave wave slots idle): config4 1 421 items of 2 passes -> 711 of 4: 78.7 -> 76.8 us per iteration. Only when that
+        // round is well filled (a half-empty round of long blocks loses: 569 blocks of 5 passes 84.3 us).
+        if (!v.fuseAgents && L == 0 && N == 1 && S > 0 && !exp_env("DOPF_STO_TARGET_ITEMS")) {
+            int cus = 256;
+            hipDeviceProp_t prop{};
+            if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+            const int slots = 3 * cus - 8, units = (S + NG - 1) / NG;
+            const int passes = (units + slots - 1) / slots;
+            if (passes >= 2 && (units + passes - 1) / passes >= (slots * 4) / 5) schunk = std::max(schunk, passes * NG);
+        }
         make_items(snode, N, schunk, sitems, nsb, nsib);
         v.stoChunk = (N == 1 && !exp_env("DOPF_NO_STO_CHUNK")) ? schunk : 0;
     }
