@@ -355,7 +355,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         v.cp_ia = 1.0 / a0; v.cp_idet = 1.0 / (a0 * a0 - v.gamma * v.gamma); v.cp_s2 = 2.0 / (a0 + v.gamma);
     }
     v.use_warm = (S > 0 && lc.stoNCH <= 3 && !(q->flags & DOPF_F_NO_WARM_START)) ? 1 : 0;
-    v.stoLean = (q->flags & DOPF_F_STO_GENERAL) ? 0 : 1;        // (the launch picks it where it applies: no lines, T == LPS * NCH, LPS <= 32)
+    v.stoLean = ((q->flags & DOPF_F_STO_GENERAL) || (unsigned long long)S * T * sizeof(double) >= (1ull << 32)) ? 0 : 1;    // (32-bit element offsets)        // (the launch picks it where it applies: no lines, T == LPS * NCH, LPS <= 32)
     v.genTT = std::min(T, 512);
     v.genR = 512 / v.genTT;
     v.genTT2 = (L == 0 && T % 2 == 0 && T / 2 <= 512) ? T / 2 : 0;

@@ -232,17 +232,21 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
 #else
         const DevView *pv = &v;
 #endif
-        const double mc = live ? pv->sto_mc[s] : 0.0, pm = live ? pv->sto_pmax[s] : 0.0, em = live ? pv->sto_emax[s] : 0.0;
-        const bool havenu = live && pv->nu_valid[s] != 0;
+        // A lane group without a storage of its own (the item's last pass) solves the item's FIRST storage again and stores nothing
+        // (gdone from the start): every load below is unconditional, no exec-mask regions around them. Element offsets are 32-bit
+        // (dopf_create offers this body only while S * T * 8 < 4 GB): base register + offset addressing, no 64-bit address arithmetic.
+        const unsigned sl = live ? (unsigned)s : (unsigned)it.a0;
+        const double mc = pv->sto_mc[sl], pm = pv->sto_pmax[sl], em = pv->sto_emax[sl];
+        const bool havenu = live && pv->nu_valid[sl] != 0;
         double A0[NCH], B0[NCH], nuv[NCH], dq[NCH];      // rD = A0 - nu, rC = B0 + nu
         double run = 0.0;
         double d0r[NCH], c0r[NCH], nur[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int t = tbase + c;
-            const size_t e = (size_t)s * T + (live ? t : 0);
-            d0r[c] = live ? pv->D[e] : 0.0; c0r[c] = live ? pv->C[e] : 0.0;
-            nur[c] = pv->nu_prev[live ? e : 0];      // (always loaded, from a valid address: sto_warm_body)
+            const unsigned e = sl * (unsigned)T + (unsigned)t;
+            d0r[c] = pv->D[e]; c0r[c] = pv->C[e];
+            nur[c] = pv->nu_prev[e];
         }
         if (PERSIST && rep == 0) {
             // the rows above are on their way; now the prices the launch's tail block publishes (agents_persist.h)
@@ -282,7 +286,8 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
         const double tolc = 1e-9 * (1.0 + em), tolE = 1e-11 * (1.0 + em), tolr = 1e-12 * (1.0 + em);
         int kind[NCH];                       // 0 free, 1 empty, 2 full
         {
-            const double inclE = scan_sum<LPS>(run, lane);
+            double inclE = run, zero_ = 0.0;
+            lz_seg_sum2<LPS>(first ? 0.0 : 1.0, inclE, zero_);          // (plain prefix sums: one segment per group)
             // (a DPP read is made by ALL lanes, then selected: inside a conditional its source lanes may be switched off, and a
             // switched-off source reads as 0)
             const double prevE = lz_prev<LPS>(inclE);
@@ -632,7 +637,7 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
 #endif
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    const size_t e = (size_t)s_ * T + tbase + c;
+                    const unsigned e = (unsigned)s_ * (unsigned)T + (unsigned)(tbase + c);
                     pw->D[e] = Dv[c];
                     pw->C[e] = Cv[c];
                     pw->nu_prev[e] = nuc[c] + 0.5 * (B0[c] - A0[c] - w * dq[c]);      // nu + theta (theta back from the step's offsets)
