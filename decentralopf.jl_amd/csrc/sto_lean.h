@@ -24,8 +24,17 @@
 // The arithmetic that decides anything (tolerances, bracket rules, the flat-segment jump, the repair rule, both release
 // passes) is sto_warm_body's; results agree to rounding (sums are associated differently).
 #pragma once
+#include <type_traits>
 
 namespace dopf {
+
+// element at a 32-bit BYTE offset from a uniform base: scalar base + vector offset addressing (the same offset serves the
+// arrays that share a layout: D, C and the stored prices) instead of a 64-bit address per access
+template <class Tp>
+__device__ __forceinline__ Tp *lz_at(Tp *base, unsigned byte_off)
+{
+    return reinterpret_cast<Tp *>(reinterpret_cast<char *>(const_cast<typename std::remove_const<Tp>::type *>(base)) + byte_off);
+}
 
 template <int CTRL>
 __device__ __forceinline__ double lz_dpp(double x)          // DPP read, lanes without a source get 0
@@ -244,9 +253,9 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int t = tbase + c;
-            const unsigned e = sl * (unsigned)T + (unsigned)t;
-            d0r[c] = pv->D[e]; c0r[c] = pv->C[e];
-            nur[c] = pv->nu_prev[e];
+            const unsigned eb = (sl * (unsigned)T + (unsigned)t) * 8u;
+            d0r[c] = *lz_at(pv->D, eb); c0r[c] = *lz_at(pv->C, eb);
+            nur[c] = *lz_at(pv->nu_prev, eb);
         }
         if (PERSIST && rep == 0) {
             // the rows above are on their way; now the prices the launch's tail block publishes (agents_persist.h)
@@ -637,10 +646,10 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
 #endif
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    const unsigned e = (unsigned)s_ * (unsigned)T + (unsigned)(tbase + c);
-                    pw->D[e] = Dv[c];
-                    pw->C[e] = Cv[c];
-                    pw->nu_prev[e] = nuc[c] + 0.5 * (B0[c] - A0[c] - w * dq[c]);      // nu + theta (theta back from the step's offsets)
+                    const unsigned eb = ((unsigned)s_ * (unsigned)T + (unsigned)(tbase + c)) * 8u;
+                    *lz_at(pw->D, eb) = Dv[c];
+                    *lz_at(pw->C, eb) = Cv[c];
+                    *lz_at(pw->nu_prev, eb) = nuc[c] + 0.5 * (B0[c] - A0[c] - w * dq[c]);      // nu + theta (theta back from the step's offsets)
                     accQ[c] += Dv[c] - Cv[c];
                     accCost += mc * (Dv[c] + Cv[c]);
                 }
