@@ -587,7 +587,7 @@ def main():
             rows = bs // (pp.T // 2) if pair else 1
             row_skip = pair and not (args.flags & _capi.F_NO_ROW_SKIP) and max(rows, -(-pp.G // 2048)) >= 8 * rows    # as dopf_create decides
             if fused:       # ONE launch does every x-update: generators and storages
-                kname, alg_b = ("k_agents" if pp.L == 0 else "k_net_agents"), whole_b
+                kname, alg_b = (("k_agents_l" if timing.get("sto_lean") else "k_agents") if pp.L == 0 else "k_net_agents"), whole_b
             else:
                 kname = ("k_gen_update_pair_skip" if row_skip else "k_gen_update_pair") if pair else "k_gen_update"
                 alg_b = gen_b + shared_b
@@ -650,7 +650,7 @@ def main():
                                                    "frac": whole_b / it_ms * 1e-6 / PEAK_GBPS,
                                                    "what": "algorithmic bytes of one iteration / per-iteration time of the timed region "
                                                            "(all launches and the gaps between them)"}}
-            vr = valu_roofline(args.workload, "k_agents" if (fused and pp.L == 0) else ("k_net_agents" if fused else kname), k_ms)
+            vr = valu_roofline(args.workload, kname, k_ms)
             if vr:
                 out["roofline"]["valu"] = vr
             if row_skip:
@@ -669,12 +669,12 @@ def main():
             out["agents_fused"], out["tail_fused"] = fused, tail
             if not fused:
                 s_ms = max(timing["sto_ms"] - ov, 1e-6)
-                out["storage_kernel"] = {"kernel": "k_sto (active-set solve; scan kernel for what it leaves over" +
+                out["storage_kernel"] = {"kernel": ("k_sto_l" if timing.get("sto_lean") else "k_sto") + " (active-set solve; scan kernel for what it leaves over" +
                                                    ("; carries the iteration's tail block)" if tail else ")") if pp.L == 0 else "k_sto_warm + k_sto_update",
                                          "bound": "fp64 VALU (segmented Newton + certificate), not HBM",
                                          "algorithmic_bytes_per_launch": sto_b, "algorithmic_bytes_moved": sto_mv, "kernel_ms": s_ms,
                                          "achieved_GBps": sto_b / s_ms * 1e-6, "frac_of_hbm_peak": sto_b / s_ms * 1e-6 / PEAK_GBPS,
-                                         "valu": valu_roofline(args.workload, "k_sto", s_ms)}
+                                         "valu": valu_roofline(args.workload, "k_sto_l" if timing.get("sto_lean") else "k_sto", s_ms)}
             if fused and world == 1 and not args.force_sharded and not args.no_side:
                 # the two halves of k_agents on their own (separate launches, DOPF_F_NO_FUSE), steady state: the generator
                 # sweep is the HBM-bound part, the storage solve the VALU-bound one
