@@ -825,6 +825,39 @@ __device__ __forceinline__ double dppd(double oldv, double src)
     return __hiloint2double(hi, lo);
 }
 
+// DPP read whose lanes without a source get 0 — one move per dword (dppd with old == src is a copy + a move per dword). For
+// callers that discard what such lanes read. (A DPP read must be made by ALL lanes: a switched-off source lane reads as 0 here.)
+template <int CTRL>
+__device__ __forceinline__ double dppz(double src)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// v_min_f64 / v_max_f64 as they are: the compiler puts a canonicalising `v_max_f64 x, x` in front of every fmin / fmax whose
+// operand was assembled from the integer halves a DPP move (or a 64-bit select) delivers. No NaN enters the chains these are used
+// in (finite values and +-inf, combined by min / max only).
+__device__ __forceinline__ double lz_min(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double lz_minabs(double a, double b)          // min(|a|, |b|)
+{
+    double r;
+    asm("v_min_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double lz_max(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double lz_clamp(double v, double lo, double hi) { return lz_min(lz_max(v, lo), hi); }      // = clampd
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ Map3 dppm(const Map3 &m)
 {
@@ -852,8 +885,8 @@ __device__ __forceinline__ void scan_maps(Map3 &m, int lane)
 template <int LPS>
 __device__ __forceinline__ double prev_lane(double x)
 {
-    if (LPS <= 16) return dppd<0x111, 0xF>(x, x);      // row_shr:1
-    return dppd<0x138, 0xF>(x, x);                     // wave_shr:1
+    if (LPS <= 16) return dppz<0x111>(x);              // row_shr:1
+    return dppz<0x138>(x);                             // wave_shr:1
 }
 
 template <int LPS>
@@ -1387,7 +1420,7 @@ __device__ __forceinline__ void seg_scan2(int &f, double &a, double &b, int lane
 #define DOPF_SEG_STEP(CTRL, RM, COND)                                                        \
     {                                                                                        \
         const int pf = __builtin_amdgcn_update_dpp(f, f, CTRL, RM, 0xF, false);              \
-        const double pa = dppd<CTRL, RM>(a, a), pb = dppd<CTRL, RM>(b, b);                   \
+        const double pa = (RM) == 0xF ? dppz<CTRL>(a) : dppd<CTRL, RM>(a, a), pb = (RM) == 0xF ? dppz<CTRL>(b) : dppd<CTRL, RM>(b, b); \
         if (COND) { if (!f) { a += pa; b += pb; } f |= pf; }                                 \
     }
     DOPF_SEG_STEP(0x111, 0xF, r >= 1)
@@ -1407,8 +1440,8 @@ __device__ __forceinline__ void seg_scan_maxmin(int &f, double &a, double &b, in
 #define DOPF_SEG_STEP(CTRL, RM, COND)                                                        \
     {                                                                                        \
         const int pf = __builtin_amdgcn_update_dpp(f, f, CTRL, RM, 0xF, false);              \
-        const double pa = dppd<CTRL, RM>(a, a), pb = dppd<CTRL, RM>(b, b);                   \
-        if (COND) { if (!f) { a = fmax(a, pa); b = fmin(b, pb); } f |= pf; }                 \
+        const double pa = (RM) == 0xF ? dppz<CTRL>(a) : dppd<CTRL, RM>(a, a), pb = (RM) == 0xF ? dppz<CTRL>(b) : dppd<CTRL, RM>(b, b); \
+        if (COND) { if (!f) { a = lz_max(a, pa); b = lz_min(b, pb); } f |= pf; }             \
     }
     DOPF_SEG_STEP(0x111, 0xF, r >= 1)
     if (LPS >= 4) DOPF_SEG_STEP(0x112, 0xF, r >= 2)
@@ -1422,10 +1455,10 @@ __device__ __forceinline__ void seg_scan_maxmin(int &f, double &a, double &b, in
 template <int LPS>
 __device__ __forceinline__ double group_max(double x)
 {
-    if (LPS >= 2) x = fmax(x, dppd<0xB1, 0xF>(x, x));
-    if (LPS >= 4) x = fmax(x, dppd<0x4E, 0xF>(x, x));
-    if (LPS >= 8) x = fmax(x, dppd<0x141, 0xF>(x, x));
-    if (LPS >= 16) x = fmax(x, dppd<0x140, 0xF>(x, x));
+    if (LPS >= 2) x = lz_max(x, dppz<0xB1>(x));
+    if (LPS >= 4) x = lz_max(x, dppz<0x4E>(x));
+    if (LPS >= 8) x = lz_max(x, dppz<0x141>(x));
+    if (LPS >= 16) x = lz_max(x, dppz<0x140>(x));
     if (LPS >= 32) x = fmax(x, __shfl_xor(x, 16));
     if (LPS >= 64) x = fmax(x, __shfl_xor(x, 32));
     return x;
@@ -1440,8 +1473,8 @@ __device__ __forceinline__ void scan_clamps_rev(double &lo, double &hi, int lane
     const int r = lane & (RL - 1);
 #define DOPF_REV_STEP(CTRL, D)                                                       \
     {                                                                                \
-        const double glo = dppd<CTRL, 0xF>(lo, lo), ghi = dppd<CTRL, 0xF>(hi, hi);   \
-        if (r + D < RL) { const double nlo = clampd(glo, lo, hi), nhi = clampd(ghi, lo, hi); lo = nlo; hi = nhi; } \
+        const double glo = dppz<CTRL>(lo), ghi = dppz<CTRL>(hi);                     \
+        if (r + D < RL) { const double nlo = lz_clamp(glo, lo, hi), nhi = lz_clamp(ghi, lo, hi); lo = nlo; hi = nhi; } \
     }
     DOPF_REV_STEP(0x101, 1)                     // row_shl:1
     if (LPS >= 4) DOPF_REV_STEP(0x102, 2)
@@ -1450,11 +1483,11 @@ __device__ __forceinline__ void scan_clamps_rev(double &lo, double &hi, int lane
 #undef DOPF_REV_STEP
     if (LPS >= 32) {                            // rows 0, 2 take the whole of the next row (its lane 0)
         const double glo = __shfl(lo, (lane | 15) + 1), ghi = __shfl(hi, (lane | 15) + 1);
-        if ((lane & 16) == 0) { const double nlo = clampd(glo, lo, hi), nhi = clampd(ghi, lo, hi); lo = nlo; hi = nhi; }
+        if ((lane & 16) == 0) { const double nlo = lz_clamp(glo, lo, hi), nhi = lz_clamp(ghi, lo, hi); lo = nlo; hi = nhi; }
     }
     if (LPS >= 64) {                            // rows 0, 1 take rows 2-3 (lane 32)
         const double glo = __shfl(lo, 32), ghi = __shfl(hi, 32);
-        if ((lane & 32) == 0) { const double nlo = clampd(glo, lo, hi), nhi = clampd(ghi, lo, hi); lo = nlo; hi = nhi; }
+        if ((lane & 32) == 0) { const double nlo = lz_clamp(glo, lo, hi), nhi = lz_clamp(ghi, lo, hi); lo = nlo; hi = nhi; }
     }
 }
 
@@ -1466,8 +1499,8 @@ __device__ __forceinline__ void scan_clamps_fwd(double &lo, double &hi, int lane
     const int r = lane & ((LPS < 16 ? LPS : 16) - 1);
 #define DOPF_FWD_STEP(CTRL, RM, COND)                                                \
     {                                                                                \
-        const double glo = dppd<CTRL, RM>(lo, lo), ghi = dppd<CTRL, RM>(hi, hi);     \
-        if (COND) { const double nlo = clampd(glo, lo, hi), nhi = clampd(ghi, lo, hi); lo = nlo; hi = nhi; } \
+        const double glo = (RM) == 0xF ? dppz<CTRL>(lo) : dppd<CTRL, RM>(lo, lo), ghi = (RM) == 0xF ? dppz<CTRL>(hi) : dppd<CTRL, RM>(hi, hi); \
+        if (COND) { const double nlo = lz_clamp(glo, lo, hi), nhi = lz_clamp(ghi, lo, hi); lo = nlo; hi = nhi; } \
     }
     DOPF_FWD_STEP(0x111, 0xF, r >= 1)                           // row_shr:1
     if (LPS >= 4) DOPF_FWD_STEP(0x112, 0xF, r >= 2)
@@ -1503,8 +1536,8 @@ __device__ __forceinline__ int scan_min_rev_i(int x, int lane)
 template <int LPS>
 __device__ __forceinline__ double next_lane(double x)
 {
-    if (LPS <= 16) return dppd<0x101, 0xF>(x, x);      // row_shl:1
-    return dppd<0x130, 0xF>(x, x);                     // wave_shl:1
+    if (LPS <= 16) return dppz<0x101>(x);              // row_shl:1
+    return dppz<0x130>(x);                             // wave_shl:1
 }
 
 template <int LPS>
@@ -1860,10 +1893,10 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
                         const double rD0 = A0[c], rC0 = B0[c];
                         const double dd = Dv[c], cc = Cv[c];
                         if (dd <= 0.0) lo = rD0 + gam * cc; else if (dd >= pm) hi = rD0 - a0 * pm + gam * cc;
-                        if (cc <= 0.0) hi = fmin(hi, -rC0 - gam * dd); else if (cc >= pm) lo = fmax(lo, a0 * pm - gam * dd - rC0);
+                        if (cc <= 0.0) hi = lz_min(hi, -rC0 - gam * dd); else if (cc >= pm) lo = lz_max(lo, a0 * pm - gam * dd - rC0);
                     }
                     if (STARTS(c)) { rl = -INFINITY; rh = INFINITY; f = 1; }
-                    rl = fmax(rl, lo); rh = fmin(rh, hi);
+                    rl = lz_max(rl, lo); rh = lz_min(rh, hi);
                     slo[c] = rl; shi[c] = rh;
                 }
                 int fl = f;
@@ -1875,7 +1908,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     seen = seen || STARTS(c);
-                    if (!seen) { slo[c] = fmax(slo[c], cl); shi[c] = fmin(shi[c], ch); }
+                    if (!seen) { slo[c] = lz_max(slo[c], cl); shi[c] = lz_min(shi[c], ch); }
                 }
             }
             double mlo[NCH], mhi[NCH];
@@ -1913,8 +1946,8 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
                         // lower-end chain: empty x -> max(mlo, x), full/open x -> mlo; upper-end chain: empty/open x -> mhi, full x -> min(mhi, x)
                         const double a_lo = mlo[c], a_hi = kind[c] == 1 ? INFINITY : mlo[c];
                         const double b_lo = kind[c] == 2 ? -INFINITY : mhi[c], b_hi = mhi[c];
-                        const double nal = clampd(alo, a_lo, a_hi), nah = clampd(ahi, a_lo, a_hi);
-                        const double nbl = clampd(blo2, b_lo, b_hi), nbh = clampd(bhi2, b_lo, b_hi);
+                        const double nal = lz_clamp(alo, a_lo, a_hi), nah = lz_clamp(ahi, a_lo, a_hi);
+                        const double nbl = lz_clamp(blo2, b_lo, b_hi), nbh = lz_clamp(bhi2, b_lo, b_hi);
                         alo = nal; ahi = nah; blo2 = nbl; bhi2 = nbh;
                     }
                 }
@@ -1922,7 +1955,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
             scan_clamps_rev<LPS>(alo, ahi, lane);
             scan_clamps_rev<LPS>(blo2, bhi2, lane);
             // ends of the feasible interval arriving from the right of this lane: (lanes to the right)(0)
-            const double rightA = next_lane<LPS>(clampd(0.0, alo, ahi)), rightB = next_lane<LPS>(clampd(0.0, blo2, bhi2));
+            const double rightA = next_lane<LPS>(lz_clamp(0.0, alo, ahi)), rightB = next_lane<LPS>(lz_clamp(0.0, blo2, bhi2));
             double flo = li == LPS - 1 ? 0.0 : rightA, fhi = li == LPS - 1 ? 0.0 : rightB;
             double nuc[NCH];                                     // the certified prices (move only inside a flat segment's interval)
 #pragma unroll
@@ -1930,12 +1963,12 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
                 const int t = tbase + c;
                 nuc[c] = nuv[c];
                 if (t < T && ISEND(c)) {
-                    flo = kind[c] == 1 ? fmax(mlo[c], flo) : mlo[c];
-                    fhi = kind[c] == 2 ? fmin(mhi[c], fhi) : mhi[c];
+                    flo = kind[c] == 1 ? lz_max(mlo[c], flo) : mlo[c];
+                    fhi = kind[c] == 2 ? lz_min(mhi[c], fhi) : mhi[c];
                     if (kind[c] != 0) {
-                        const double tn = 1e-10 * (1.0 + fmin(fabs(flo), fabs(fhi)));
+                        const double tn = 1e-10 * (1.0 + lz_minabs(flo, fhi));
                         if (flo > fhi + tn) { okk = false; nkind[c] = 0; }      // wrong sign: release the contact
-                        nuc[c] = clampd(nuv[c], flo, fmax(flo, fhi));
+                        nuc[c] = lz_clamp(nuv[c], flo, lz_max(flo, fhi));
                     }
                 }
             }
@@ -1963,8 +1996,8 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
                             // upper bound min(mhi, .) behind an empty contact, none otherwise
                             const double l_lo = kind[c] == 2 ? mlo[c] : -INFINITY, l_hi = kind[c] == 2 ? INFINITY : -INFINITY;
                             const double u_lo = kind[c] == 1 ? -INFINITY : INFINITY, u_hi = kind[c] == 1 ? mhi[c] : INFINITY;
-                            const double a1 = clampd(Llo, l_lo, l_hi), a2 = clampd(Lhi, l_lo, l_hi);
-                            const double b1 = clampd(Ulo, u_lo, u_hi), b2 = clampd(Uhi, u_lo, u_hi);
+                            const double a1 = lz_clamp(Llo, l_lo, l_hi), a2 = lz_clamp(Lhi, l_lo, l_hi);
+                            const double b1 = lz_clamp(Ulo, u_lo, u_hi), b2 = lz_clamp(Uhi, u_lo, u_hi);
                             Llo = a1; Lhi = a2; Ulo = b1; Uhi = b2;
                         }
                     }
@@ -1976,8 +2009,8 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
                     for (int c = 0; c < NCH; ++c) {
                         const int t = tbase + c;
                         if (t < T && ISEND(c)) {
-                            const double glo = fmax(mlo[c], pin), ghi = fmin(mhi[c], phin);
-                            const double tn = 1e-10 * (1.0 + fmin(fabs(glo), fabs(ghi)));
+                            const double glo = lz_max(mlo[c], pin), ghi = lz_min(mhi[c], phin);
+                            const double tn = 1e-10 * (1.0 + lz_minabs(glo, ghi));
                             fd_[t] = glo > ghi + tn ? 1.0 : 0.0;           // (fd_: the Newton loop's scratch, free here; indexed by segment end)
                             pin = kind[c] == 2 ? glo : -INFINITY;
                             phin = kind[c] == 1 ? ghi : INFINITY;

@@ -59,28 +59,6 @@ __device__ __forceinline__ double lz_dpp_id(double x, double idv)
     return __hiloint2double(hi, lo);
 }
 
-// v_min_f64 / v_max_f64 as they are: the compiler puts a canonicalising `v_max_f64 x, x` in front of every fmin / fmax whose
-// operand was assembled from the integer halves a DPP move delivers (a third of the certificate's arithmetic). No NaN
-// enters these chains (finite values and +-inf, combined by min / max only).
-__device__ __forceinline__ double lz_min(double a, double b)
-{
-    double r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ double lz_minabs(double a, double b)          // min(|a|, |b|)
-{
-    double r;
-    asm("v_min_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ double lz_max(double a, double b)
-{
-    double r;
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 template <int LPS>
 __device__ __forceinline__ double lz_prev(double x)          // previous lane (the group's first lane: unspecified, finite)
 {
