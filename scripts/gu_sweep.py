@@ -1,5 +1,7 @@
 """Experiment: generator rows in flight per lane (build-time DOPF_GU) x generator blocks (DOPF_GEN_TARGET_ITEMS) in the fused
-x-update launch of config2: python scripts/gu_sweep.py lib1.so[,lib2.so...] items1,items2,...   (settled state, graph replay)"""
+x-update launch of config2: python scripts/gu_sweep.py lib1.so[,lib2.so...] items1,items2,...   (settled state, graph replay).
+The libraries must be built with -DDOPF_EXPERIMENTS (DOPF_HIPCC_FLAGS=-DDOPF_EXPERIMENTS scripts/build_lib.sh out.so): the shipped
+library does not read tuning knobs from the environment."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch
