@@ -2171,10 +2171,14 @@ __device__ DOPF_CALL_ATTR void sto_cold_lines_call(const DevView *self, const in
 #ifndef DOPF_WARM_WAVES
 #define DOPF_WARM_WAVES 2
 #endif
-template <int LPS, int NCH, bool LINES>
+template <int LPS, int NCH, bool LINES, bool LEAN = false>
 __global__ __launch_bounds__(256, DOPF_WARM_WAVES) void k_sto_warm(DevView v)
 {
-    const int left = sto_warm_body<LPS, NCH, LINES>(v, blockIdx.x, v.st->halt);         // ends on a __syncthreads
+    // (networks, LEAN: the lean body where every table of the item's node is empty — the settled state — else the general one.
+    // A template argument, not a branch on v.stoLean: with both bodies in one function the general one ran 6 % slower, measured)
+    static_assert(LINES || !LEAN, "copper plates: k_sto_l");
+    const int left = LEAN ? sto_lean_body<LPS, NCH, false, false, true, false>(v, blockIdx.x, v.st->halt)
+                          : sto_warm_body<LPS, NCH, LINES>(v, blockIdx.x, v.st->halt);         // ends on a __syncthreads
     if (left < 0) return;                                                               // halted
     if (LINES && v.coldInWarm) {
         if (left == 0) {                         // (what the scan body writes when there is nothing for it)
@@ -2193,7 +2197,7 @@ __global__ __launch_bounds__(256, DOPF_WARM_WAVES) void k_sto_warm(DevView v)
 // launch: a chain of dependent round trips), the generator items behind them in 256-thread blocks that pass through the
 // wave slots the storages leave free. Alone, either launch is a few hundred short blocks bound by its own latency chain
 // (configs[3]'s share: 12 + 13 us and a kernel boundary); together they overlap.
-template <int LPS, int NCH>
+template <int LPS, int NCH, bool LEAN>
 __global__ __launch_bounds__(256, DOPF_WARM_WAVES) void k_net_agents(DevView v)
 {
     const int nS = v.nStoItems;
@@ -2213,7 +2217,8 @@ __global__ __launch_bounds__(256, DOPF_WARM_WAVES) void k_net_agents(DevView v)
         if (2 * v.genTT256 >= v.T) gen_lines_body2<256, DOPF_NET_GEN_FLIGHT>(v, gi, v.genTT256, v.genR);
         else gen_lines_body<256, DOPF_NET_GEN_FLIGHT>(v, gi, v.genTT256, v.genR);
     } else {
-        const int left = sto_warm_body<LPS, NCH, true>(v, si, v.st->halt);             // ends on a __syncthreads
+        const int left = LEAN ? sto_lean_body<LPS, NCH, false, false, true, false>(v, si, v.st->halt)
+                              : sto_warm_body<LPS, NCH, true>(v, si, v.st->halt);                  // ends on a __syncthreads
         if (left < 0) return;                                                           // halted
         if (left == 0) {                     // (what the scan body writes when there is nothing for it)
             for (int t = threadIdx.x; t < v.T; t += 256) v.part_sinj[(size_t)si * v.T + t] = 0.0;
@@ -2279,16 +2284,16 @@ __global__ __launch_bounds__(256, 3) void k_agents(DevView v)
 #ifndef DOPF_LEAN_STO_WAVES
 #define DOPF_LEAN_STO_WAVES 3
 #endif
-template <int LPS, int NCH, bool TAIL>
+template <int LPS, int NCH, bool TAIL, bool FULLT = true>
 __global__ __launch_bounds__(256, DOPF_LEAN_STO_WAVES) void k_sto_l(DevView v)
 {
     if (TAIL && (int)blockIdx.x == v.nStoItems) { tail_block(v.self); return; }
-    const int left = sto_lean_body<LPS, NCH, TAIL>(v, blockIdx.x, v.st->halt);
+    const int left = sto_lean_body<LPS, NCH, TAIL, false, false, FULLT>(v, blockIdx.x, v.st->halt);
     if (left < 0) return;
-    sto_cold_body<LPS, NCH, false, TAIL, true>(v, blockIdx.x, left);
+    sto_cold_body<LPS, NCH, false, TAIL, FULLT>(v, blockIdx.x, left);
 }
 
-template <int LPS, int NCH, bool SKIP, bool TAIL>
+template <int LPS, int NCH, bool SKIP, bool TAIL, bool FULLT = true>
 __global__ __launch_bounds__(256, 3) void k_agents_l(DevView v)
 {
     const int nS = v.nStoItems;
@@ -2302,8 +2307,8 @@ __global__ __launch_bounds__(256, 3) void k_agents_l(DevView v)
         else gen_pair_body<256, TAIL, true>(v, blockIdx.x - nS);
     } else {
         if ((int)blockIdx.x < nS) {
-            const int left = sto_lean_body<LPS, NCH, TAIL>(v, blockIdx.x, v.st->halt);
-            if (left >= 0) sto_cold_body<LPS, NCH, false, TAIL, true>(v, blockIdx.x, left);
+            const int left = sto_lean_body<LPS, NCH, TAIL, false, false, FULLT>(v, blockIdx.x, v.st->halt);
+            if (left >= 0) sto_cold_body<LPS, NCH, false, TAIL, FULLT>(v, blockIdx.x, left);
         } else {
             if (v.st->halt) return;
             gen_pair_skip_body<256, TAIL>(v, blockIdx.x - nS);
@@ -2351,12 +2356,12 @@ static void launch_sto_t(const DevView &v, hipStream_t s)
 #else
         const bool full = v.T == LPS * NC;
 #endif
-        if constexpr (LPS <= 32) {
-            if (full && v.stoLean) {
-                if (v.tail) hipLaunchKernelGGL((k_sto_l<LPS, NC, true>), dim3(v.nStoItems + 1), dim3(256), 0, s, v);
-                else hipLaunchKernelGGL((k_sto_l<LPS, NC, false>), dim3(v.nStoItems), dim3(256), 0, s, v);
-                return;
-            }
+        if (v.stoLean) {
+            if (v.tail) { if (full) hipLaunchKernelGGL((k_sto_l<LPS, NC, true, true>), dim3(v.nStoItems + 1), dim3(256), 0, s, v);
+                          else hipLaunchKernelGGL((k_sto_l<LPS, NC, true, false>), dim3(v.nStoItems + 1), dim3(256), 0, s, v); }
+            else { if (full) hipLaunchKernelGGL((k_sto_l<LPS, NC, false, true>), dim3(v.nStoItems), dim3(256), 0, s, v);
+                   else hipLaunchKernelGGL((k_sto_l<LPS, NC, false, false>), dim3(v.nStoItems), dim3(256), 0, s, v); }
+            return;
         }
         if (v.tail) {
             if (full) hipLaunchKernelGGL((k_sto<LPS, NC, false, true, true>), dim3(v.nStoItems + 1), dim3(256), 0, s, v);
@@ -2368,7 +2373,10 @@ static void launch_sto_t(const DevView &v, hipStream_t s)
         return;
     }
     // with lines the two kernels stay apart: fused, the warm part runs 40 % slower (255 VGPRs, measured)
-    if (v.use_warm) hipLaunchKernelGGL((k_sto_warm<LPS, (NCH <= 3 ? NCH : 3), true>), dim3(v.nStoItems), dim3(256), 0, s, v);
+    if (v.use_warm) {
+        if (v.stoLean && v.L > 0) hipLaunchKernelGGL((k_sto_warm<LPS, (NCH <= 3 ? NCH : 3), true, true>), dim3(v.nStoItems), dim3(256), 0, s, v);
+        else hipLaunchKernelGGL((k_sto_warm<LPS, (NCH <= 3 ? NCH : 3), true, false>), dim3(v.nStoItems), dim3(256), 0, s, v);
+    }
     if (v.use_warm && v.L > 0 && v.coldInWarm) return;            // the warm kernel has called the scan body where needed
     if (v.L > 0) hipLaunchKernelGGL((k_sto_update<LPS, NCH, true>), dim3(v.nStoItems), dim3(256), 0, s, v);
     else hipLaunchKernelGGL((k_sto_update<LPS, NCH, false>), dim3(v.nStoItems), dim3(256), 0, s, v);
@@ -2383,14 +2391,13 @@ static void launch_agents_t(const DevView &v, hipStream_t s)
 #else
     const bool fullA = v.T == LPS * NCH;
 #endif
-    if constexpr (LPS <= 32) {
-        if (fullA && v.stoLean) {
-#define DOPF_AGL(SKIP_, TAIL_) hipLaunchKernelGGL((k_agents_l<LPS, NCH, SKIP_, TAIL_>), grid, dim3(256), 0, s, v);
-            if (v.tail) { if (v.genSkip) DOPF_AGL(true, true) else DOPF_AGL(false, true) }
-            else { if (v.genSkip) DOPF_AGL(true, false) else DOPF_AGL(false, false) }
+    if (v.stoLean) {
+#define DOPF_AGL(SKIP_, TAIL_) { if (fullA) hipLaunchKernelGGL((k_agents_l<LPS, NCH, SKIP_, TAIL_, true>), grid, dim3(256), 0, s, v); \
+                               else hipLaunchKernelGGL((k_agents_l<LPS, NCH, SKIP_, TAIL_, false>), grid, dim3(256), 0, s, v); }
+        if (v.tail) { if (v.genSkip) DOPF_AGL(true, true) else DOPF_AGL(false, true) }
+        else { if (v.genSkip) DOPF_AGL(true, false) else DOPF_AGL(false, false) }
 #undef DOPF_AGL
-            return;
-        }
+        return;
     }
 #define DOPF_AG(SKIP_, TAIL_) { if (fullA) hipLaunchKernelGGL((k_agents<LPS, NCH, SKIP_, TAIL_, true>), grid, dim3(256), 0, s, v); \
                               else hipLaunchKernelGGL((k_agents<LPS, NCH, SKIP_, TAIL_, false>), grid, dim3(256), 0, s, v); }
@@ -2425,7 +2432,9 @@ void launch_agents_persist(const DevView &v, const Launch &lc, hipStream_t s)
 void launch_net_agents(const DevView &v, const Launch &lc, hipStream_t s)
 {
     const dim3 grid(v.nStoItems + v.nGenItems);
-#define DOPF_CASE(LPS_, NCH_) if (lc.stoLPS == LPS_ && lc.stoNCH == NCH_) { hipLaunchKernelGGL((k_net_agents<LPS_, NCH_>), grid, dim3(256), 0, s, v); return; }
+#define DOPF_CASE(LPS_, NCH_) if (lc.stoLPS == LPS_ && lc.stoNCH == NCH_) { \
+        if (v.stoLean) hipLaunchKernelGGL((k_net_agents<LPS_, NCH_, true>), grid, dim3(256), 0, s, v); \
+        else hipLaunchKernelGGL((k_net_agents<LPS_, NCH_, false>), grid, dim3(256), 0, s, v); return; }
     DOPF_CASE(8, 1) DOPF_CASE(8, 2) DOPF_CASE(8, 3)
     DOPF_CASE(16, 3)
     DOPF_CASE(32, 3)

@@ -3,8 +3,9 @@
 // Included by kernels_agents.hip after the helpers it shares with sto_warm_body (box2, scan_sum, the segmented max/min
 // scan, the clamp-map scans of the left-to-right release pass, acc_add). Replaces optimize_subproblem(::Storage)
 // (reference src/optimization/subproblems.jl:107-207) exactly as sto_warm_body does — same contact-set guess, same
-// bracketed Newton, same KKT certificate and repair rule, same hand-over to the scan body, same LDS protocol — for the
-// case the headline configurations run: no lines, horizon T == LPS * NCH, LPS <= 32. What changed is HOW each step is
+// bracketed Newton, same KKT certificate and repair rule, same hand-over to the scan body, same LDS protocol. First written
+// for the case the headline configurations run (no lines, horizon T == LPS * NCH, LPS <= 32), then widened: LPS = 64, horizons
+// that end inside the lane group (FULLT = false), and network items whose price tables are empty (LINES). What changed is HOW each step is
 // written (profiles/r03_valu.json: 3 177 vector instructions per wave on config4, every one 4 cycles; the static mix
 // was 30 % moves and 17 % selects around ~180 exec-mask regions):
 //   * segment sums without selects: a step that starts a segment carries keep = 0.0, every other step keep = 1.0, and the
@@ -59,6 +60,15 @@ __device__ __forceinline__ double lz_dpp_id(double x, double idv)
     return __hiloint2double(hi, lo);
 }
 
+// DPP read under a row mask: rows outside the mask (and lanes without a source) keep `idv`
+template <int CTRL, int RM>
+__device__ __forceinline__ double lz_dpp_rm(double x, double idv)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(idv), __double2loint(x), CTRL, RM, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(idv), __double2hiint(x), CTRL, RM, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
 template <int LPS>
 __device__ __forceinline__ double lz_prev(double x)          // previous lane (the group's first lane: unspecified, finite)
 {
@@ -93,8 +103,20 @@ __device__ __forceinline__ void lz_seg_sum2(double k, double &a, double &b)
     if (LPS >= 4) DOPF_LZ_STEP(0x112)
     if (LPS >= 8) DOPF_LZ_STEP(0x114)
     if (LPS >= 16) DOPF_LZ_STEP(0x118)
-    if (LPS >= 32) DOPF_LZ_STEP(0x142)                       // row_bcast:15 (rows 0 and 2 start groups: their keep is 0 by now)
+    if (LPS == 32) DOPF_LZ_STEP(0x142)                       // row_bcast:15 (rows 0 and 2 start groups: their keep is 0 by now)
 #undef DOPF_LZ_STEP
+    if (LPS >= 64) {
+        // one group per wave: rows 1 and 3 take the row before them (its last lane), then rows 2 and 3 take lane 31 — the rows
+        // that are not meant read the identity (row masks; their old value is what they keep)
+#define DOPF_LZ_STEP64(CTRL, RM)                                                     \
+        {                                                                            \
+            const double pa = lz_dpp_rm<CTRL, RM>(a, 0.0), pb = lz_dpp_rm<CTRL, RM>(b, 0.0), pk = lz_dpp_rm<CTRL, RM>(k, 1.0); \
+            a = fma(pa, k, a); b = fma(pb, k, b); k *= pk;                            \
+        }
+        DOPF_LZ_STEP64(0x142, 0xA)
+        DOPF_LZ_STEP64(0x143, 0xC)
+#undef DOPF_LZ_STEP64
+    }
 }
 
 // Suffix scans of the gated chains: lane composite (M, G) stands for x -> max(M, min(G, x)) (lower ends) resp.
@@ -124,6 +146,13 @@ __device__ __forceinline__ void lz_chain_scan(double &M, double &G, int lane)
             else { M = lz_min(M, lz_max(G, pM)); G = lz_max(G, pG); }
         }
     }
+    if (LPS >= 64) {                                         // rows 0, 1 take rows 2-3 (lane 32)
+        const double pM = __shfl(M, 32), pG = __shfl(G, 32);
+        if ((lane & 32) == 0) {
+            if (LOWER) { M = lz_max(M, lz_min(G, pM)); G = lz_min(G, pG); }
+            else { M = lz_min(M, lz_max(G, pM)); G = lz_max(G, pG); }
+        }
+    }
 }
 
 // inclusive segmented prefix (max of a, min of b) over the lanes of each group; K = +inf if no segment starts inside the
@@ -141,8 +170,18 @@ __device__ __forceinline__ void lz_seg_maxmin(double K, double &a, double &b)
     if (LPS >= 4) DOPF_LZ_STEP(0x112)
     if (LPS >= 8) DOPF_LZ_STEP(0x114)
     if (LPS >= 16) DOPF_LZ_STEP(0x118)
-    if (LPS >= 32) DOPF_LZ_STEP(0x142)
+    if (LPS == 32) DOPF_LZ_STEP(0x142)
 #undef DOPF_LZ_STEP
+    if (LPS >= 64) {
+#define DOPF_LZ_STEP64(CTRL, RM)                                                     \
+        {                                                                            \
+            const double pa = lz_dpp_rm<CTRL, RM>(a, -INFINITY), pb = lz_dpp_rm<CTRL, RM>(b, INFINITY), pK = lz_dpp_rm<CTRL, RM>(K, INFINITY); \
+            a = lz_max(a, lz_min(K, pa)); b = lz_min(b, lz_max(-K, pb)); K = lz_min(K, pK); \
+        }
+        DOPF_LZ_STEP64(0x142, 0xA)
+        DOPF_LZ_STEP64(0x143, 0xC)
+#undef DOPF_LZ_STEP64
+    }
 }
 
 // persistent iterations (agents_persist.h): Status::pseq = number of dual updates published inside launches (low 30 bits) | the halt
@@ -164,16 +203,30 @@ __device__ __forceinline__ unsigned persist_wait_word(Status *st, const unsigned
 // read past the caches, and the accumulator set is the caller's (`ppar`), not the status block's word.
 // (PERSIST, pwant != 0: the wait for the previous iteration's prices happens INSIDE, behind the first pass's row loads — those
 // do not depend on the prices; returns -1 when the wait found the halted state or timed out: nothing stored)
-template <int LPS, int NCH, bool TAIL, bool PERSIST = false>
+// LINES: an item of storages at a node of a network whose tables are EMPTY for every timestep (no kink of Psi inside the node's
+// window: the settled state) — the copper plate's closed form with (Psi(0), slope) of the (node, timestep) in place of (theta, gamma);
+// an item that meets a non-empty table is handed to the general body (sto_warm_body) as a whole.
+// FULLT = false: the horizon ends inside the lane group (T < LPS * NCH): the steps behind it are inert (no charge, no slope, no
+// contact) and sit in a segment of their own behind step T - 1, which always ends one.
+// (the general body as a function of its own: inlined behind the table test, its registers crowd the lean body's)
+template <int LPS, int NCH>
+__device__ __attribute__((noinline)) int sto_warm_lines_call(const DevView *self, const int blk, const int halt)
+{
+    return sto_warm_body<LPS, NCH, true>(*self, blk, halt);
+}
+
+template <int LPS, int NCH, bool TAIL, bool PERSIST = false, bool LINES = false, bool FULLT = true>
 __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, const int halt, const int ppar = 0, const unsigned pwant = 0u)
 {
-    static_assert(LPS <= 32 && NCH <= 8, "the row_bcast steps assume at most two rows per group; 4 pattern bits per step");
-    constexpr int NG = 256 / LPS, T = LPS * NCH;
+    static_assert(LPS <= 64 && NCH <= 8, "4 pattern bits per step");
+    static_assert(!(PERSIST && (LINES || !FULLT)) && !(TAIL && LINES), "persistent iterations / the tail in the launch: full-horizon copper plates");
+    constexpr int NG = 256 / LPS, TP = LPS * NCH;
+    const int T = FULLT ? TP : v.T;
     constexpr int MAXR = 16;                 // contact-set rounds per storage
     constexpr int MAXN = 40;                 // Newton iterations per round
     constexpr int BIG = 0x3fffffff;
-    __shared__ double red[NG * T];           // nuL: price of the segment that ends here
-    __shared__ double fdL[NG * T];           // flat segment: signed distance to the nearest kink ahead; release flags of the left-to-right pass
+    __shared__ double red[NG * TP];          // nuL: price of the segment that ends here
+    __shared__ double fdL[NG * TP];          // flat segment: signed distance to the nearest kink ahead; release flags of the left-to-right pass
     const int tid = threadIdx.x, lane = tid & 63, li = tid & (LPS - 1), grp = tid / LPS;
     const int gbase = lane & ~(LPS - 1);
     Item it;
@@ -183,8 +236,35 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
     const double w = v.w_prox, gam = v.gamma;
     const double a0 = w + gam, ia0 = v.cp_ia, idet0 = v.cp_idet, s20 = v.cp_s2;      // (host: the same expressions)
     const int tbase = li * NCH;
-    double *nuL = red + grp * T, *fd_ = fdL + grp * T;
+    double *nuL = red + grp * TP, *fd_ = fdL + grp * TP;
     const bool first = li == 0, last = li == LPS - 1;
+    // step c of this lane: inside the horizon / the horizon's last step
+#define LZ_IN(c) (FULLT || tbase + (c) < T)
+#define LZ_TLAST(c) (FULLT ? (last && (c) == NCH - 1) : (tbase + (c) == T - 1))
+    // box2 coefficients of step c: a = w + kappa, b = kappa with kappa = gamma on the copper plate, the slope of the step's Psi with lines
+    double lp0[NCH], kapL[NCH], iaL[NCH], idetL[NCH], s2L[NCH];
+#define LZ_KAP(c) (LINES ? kapL[c] : gam)
+#define LZ_AA(c) (LINES ? w + kapL[c] : a0)
+#define LZ_IA(c) (LINES ? iaL[c] : ia0)
+#define LZ_IDET(c) (LINES ? idetL[c] : idet0)
+#define LZ_S2(c) (LINES ? s2L[c] : s20)
+    if (LINES) {
+        int nonlin = 0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            lp0[c] = 0.0; kapL[c] = gam; iaL[c] = ia0; idetL[c] = idet0; s2L[c] = s20;
+            if (LZ_IN(c)) {
+                const size_t at = (size_t)it.node + (size_t)N * (tbase + c);
+                const int m_ = v.tb_m[at];                   // (all three loaded at once: sto_warm_body)
+                const double p0_ = v.tb_psi0[at], k_ = v.tb_slope[at * (v.M2 + 1)];
+                nonlin |= m_ != 0;
+                lp0[c] = p0_; kapL[c] = k_;
+                lin_coef(w, 1.0 / w, k_, iaL[c], idetL[c], s2L[c]);
+            }
+        }
+        // (block-uniform: the lanes of one group see every timestep of the item's node)
+        if (__syncthreads_or(nonlin)) return sto_warm_lines_call<LPS, NCH>(v.self, blk, halt);
+    }
 
     double accQ[NCH];
     double accCost = 0.0;
@@ -194,12 +274,12 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
     // price + gamma * imbalance of the lane's steps: the same for every storage pass of the block. Parked in LDS (one read per
     // step and pass) instead of registers (the kernel sits at its register limit) or two more loads per step and pass, whose
     // addresses cost a v_readlane each once the solve has taken the scalar registers.
-    __shared__ double th0L[T];
+    __shared__ double th0L[TP];
     __shared__ int goL;
-    if (!PERSIST) {
+    if (!PERSIST && !LINES) {
         if (tid < LPS) {
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) th0L[tbase + c] = v.price[it.node + N * (tbase + c)] + gam * v.s[tbase + c];
+            for (int c = 0; c < NCH; ++c) th0L[tbase + c] = LZ_IN(c) ? v.price[it.node + N * (tbase + c)] + gam * v.s[tbase + c] : 0.0;
         }
         __syncthreads();
     }
@@ -231,9 +311,10 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int t = tbase + c;
-            const unsigned eb = (sl * (unsigned)T + (unsigned)t) * 8u;
+            const unsigned eb = (sl * (unsigned)T + (unsigned)(LZ_IN(c) ? t : 0)) * 8u;
             d0r[c] = *lz_at(pv->D, eb); c0r[c] = *lz_at(pv->C, eb);
             nur[c] = *lz_at(pv->nu_prev, eb);
+            if (!LZ_IN(c)) { d0r[c] = 0.0; c0r[c] = 0.0; nur[c] = 0.0; }
         }
         if (PERSIST && rep == 0) {
             // the rows above are on their way; now the prices the launch's tail block publishes (agents_persist.h)
@@ -260,12 +341,14 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
         for (int c = 0; c < NCH; ++c) {
             const int t = tbase + c;
             const double d0 = d0r[c], c0 = c0r[c], nu_st = nur[c];
-            const double th0 = th0L[t];
-            const double theta = th0 - gam * (d0 - c0);
+            // copper plate: theta = price + gamma (imbalance - own injection); lines: Psi(0) of the node's linear piece - slope * own injection
+            const double theta = LINES ? lp0[c] - kapL[c] * (d0 - c0) : th0L[t] - gam * (d0 - c0);
             dq[c] = c0 - d0;
             run += c0 - d0;
             A0[c] = w * d0 - mc - theta; B0[c] = w * c0 - mc + theta;
-            nuv[c] = havenu ? nu_st - theta : 0.0;       // the warm start follows the price move: nu + theta is what is stored
+            // (copper plate: the warm start follows the price move — nu + theta is what is stored; lines: nu itself, as sto_warm_body)
+            nuv[c] = havenu ? (LINES ? nu_st : nu_st - theta) : 0.0;
+            if (!LZ_IN(c)) { A0[c] = -1e300; B0[c] = -1e300; nuv[c] = 0.0; }     // behind the horizon: D = C = 0 at every price, no slope
         }
         if (rep == 0 && halt) return -1;         // (uniform; the loads above are on their way, nothing has been stored)
 
@@ -282,7 +365,7 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 eo += dq[c];
-                kind[c] = eo <= tolc ? 1 : (eo >= em - tolc ? 2 : 0);
+                kind[c] = !LZ_IN(c) ? 0 : (eo <= tolc ? 1 : (eo >= em - tolc ? 2 : 0));
             }
         }
 
@@ -301,9 +384,11 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
             {
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    en[c] = kind[c] != 0 || (last && c == NCH - 1);
+                    en[c] = kind[c] != 0 || LZ_TLAST(c);
                 }
-                const int pkd = lz_previ<LPS>(kind[NCH - 1]);        // (the previous lane's last step is never step T - 1)
+                // what the previous lane's last step ends: 0 nothing, 1 a segment at level 0 (an empty contact, or — ragged horizons — the
+                // open last segment), 2 a segment at level emax. (Full horizons: that step is never step T - 1, so its kind says it all.)
+                const int pkd = lz_previ<LPS>(FULLT ? kind[NCH - 1] : (en[NCH - 1] ? (kind[NCH - 1] == 2 ? 2 : 1) : 0));
                 st0 = first || pkd != 0;
                 double run_k = 1.0;
 #pragma unroll
@@ -325,14 +410,14 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
 #pragma unroll
                 for (int c = NCH - 1; c >= 0; --c) {
                     if (en[c]) carry = tbase + c;
-                    send[c] = carry < T ? carry : T - 1;     // (a group that is done may hold anything: any valid slot)
+                    send[c] = carry < TP ? carry : TP - 1;   // (steps behind the horizon, groups that are done: any valid slot)
                 }
 #pragma unroll
                 for (int c = 0; c < NCH; ++c)
                     if (en[c]) nuL[tbase + c] = kind[c] != 0 ? nuv[c] : 0.0;      // one price per segment; open last segment: 0
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) nuv[c] = nuL[send[c]];
+                for (int c = 0; c < NCH; ++c) nuv[c] = LZ_IN(c) ? nuL[send[c]] : 0.0;
                 __builtin_amdgcn_wave_barrier();
             }
 
@@ -353,7 +438,7 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     double dd, cc, s1;
-                    box2(a0, gam, ia0, idet0, s20, A0[c] - nuv[c], B0[c] + nuv[c], pm, dd, cc, s1);
+                    box2(LZ_AA(c), LZ_KAP(c), LZ_IA(c), LZ_IDET(c), LZ_S2(c), A0[c] - nuv[c], B0[c] + nuv[c], pm, dd, cc, s1);
                     Dv[c] = dd; Cv[c] = cc; sl[c] = s1;          // (of the last evaluation: the certified values when the round passes)
                     // the step's active set: each of D, C at 0 / inside / at pm (a step that jumps from one bound to the other
                     // has changed its piece although "inside or not" reads the same)
@@ -413,7 +498,7 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) {
                         double du = INFINITY, dn = INFINITY;
-                        const double sh = gam * (Dv[c] - Cv[c]);
+                        const double sh = LZ_KAP(c) * (Dv[c] - Cv[c]);
                         const double bD = A0[c] - sh, bC = -B0[c] - sh, wp = w * pm;
                         const double cand[4] = {bD, bD - wp, bC, bC + wp};
 #pragma unroll
@@ -471,7 +556,7 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    const double nn = nuL[send[c]];
+                    const double nn = LZ_IN(c) ? nuL[send[c]] : 0.0;
                     px[c] = fma(ps[c], nn - nuv[c], px[c]);          // where the step lands if every step of the wave stays on its piece
                     nuv[c] = nn;
                 }
@@ -491,7 +576,7 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
                 for (int c = 0; c < NCH; ++c) {
                     const double dd = Dv[c], cc = Cv[c];
                     // D = 0: nu >= A0 + gam C; D = pm: nu <= that - a pm; C = 0: nu <= -B0 - gam D; C = pm: nu >= that + a pm
-                    const double lD = fma(gam, cc, A0[c]), hC = -fma(gam, dd, B0[c]), apm = a0 * pm;
+                    const double lD = fma(LZ_KAP(c), cc, A0[c]), hC = -fma(LZ_KAP(c), dd, B0[c]), apm = LZ_AA(c) * pm;
                     double lo = dd <= 0.0 ? lD : -INFINITY;
                     double hi = (dd > 0.0 && dd >= pm) ? lD - apm : INFINITY;
                     hi = lz_min(hi, cc <= 0.0 ? hC : INFINITY);
@@ -592,7 +677,7 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
                     const int sendNext = next_lane_i<LPS>(send[0]);        // the segment the next lane's first step belongs to
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) {
-                        if (!(last && c == NCH - 1) && en[c] && kind[c] != 0) {
+                        if (!LZ_TLAST(c) && en[c] && kind[c] != 0) {
                             const int sn = c + 1 < NCH ? send[c + 1 < NCH ? c + 1 : c] : sendNext;
                             if (fwd && fd_[sn] != 0.0) { okk = false; nkind[c] = 0; }
                         }
@@ -601,7 +686,7 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
                 }
             }
 #ifdef LZ_DEBUG_PRINT
-            if (s == LZ_DEBUG_PRINT && v.st->iters_total == 2) {
+            if (s == LZ_DEBUG_PRINT && v.st->iters_total == LZ_DEBUG_ITER) {
                 for (int c = 0; c < NCH; ++c)
                     printf("r%d t%2d kind %d->%d en %d nuv %.6f D %.5f C %.5f px %.6f ps %.4f mlo %.6f mhi %.6f nuc %.6f okk %d nconv %d gdone %d A0 %.5f B0 %.5f\n", round, tbase + c, kind[c], nkind[c], (int)en[c], nuv[c], Dv[c], Cv[c], px[c], ps[c], mlo[c], mhi[c], nuc[c], (int)okk, (int)nconv, (int)gdone, A0[c], B0[c]);
             }
@@ -624,10 +709,13 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
 #endif
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
+                    if (!LZ_IN(c)) continue;
                     const unsigned eb = ((unsigned)s_ * (unsigned)T + (unsigned)(tbase + c)) * 8u;
                     *lz_at(pw->D, eb) = Dv[c];
                     *lz_at(pw->C, eb) = Cv[c];
-                    *lz_at(pw->nu_prev, eb) = nuc[c] + 0.5 * (B0[c] - A0[c] - w * dq[c]);      // nu + theta (theta back from the step's offsets)
+                    // copper plate: nu + theta (theta back from the step's offsets); lines: nu
+                    *lz_at(pw->nu_prev, eb) = LINES ? nuc[c] : nuc[c] + 0.5 * (B0[c] - A0[c] - w * dq[c]);
+                    if (LINES && (pw->keepDeltas || pw->walk_any[tbase + c])) *lz_at(pw->dltS, eb) = (Dv[c] - Cv[c]) + dq[c];
                     accQ[c] += Dv[c] - Cv[c];
                     accCost += mc * (Dv[c] + Cv[c]);
                 }
@@ -672,10 +760,10 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
         double x = accQ[c];
         if (LPS <= 8) x += lz_dpp<0x128>(x);                 // row_ror:8 (the lane 8 further on, modulo the row)
         if (LPS <= 16) x += __shfl_xor(x, 16);
-        x += __shfl_xor(x, 32);
+        if (LPS <= 32) x += __shfl_xor(x, 32);
         accQ[c] = x;
     }
-    __shared__ double wsumS[4][T];
+    __shared__ double wsumS[4][TP];
     __shared__ double wcostS[4];
     __shared__ int wfailS[4];
     {
@@ -704,6 +792,7 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int t = tbase + c;
+            if (!LZ_IN(c)) continue;
             const double sum = ((wsumS[0][t] + wsumS[1][t]) + wsumS[2][t]) + wsumS[3][t];
             if (TAIL && blockFail == 0) acc_add(tv, tpar, t, sum, tv.scaleInj);
             else pf->part_sinj_w[(size_t)blk * T + t] = sum;
@@ -717,6 +806,13 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
     }
     if (blockFail != 0) __syncthreads();
     return blockFail;
+#undef LZ_IN
+#undef LZ_TLAST
+#undef LZ_KAP
+#undef LZ_AA
+#undef LZ_IA
+#undef LZ_IDET
+#undef LZ_S2
 }
 
 }  // namespace dopf

@@ -122,7 +122,8 @@ typedef struct dopf_params {
                                    dopf_last_call_ms returns the device-side span of the last call's iterations (no host launch
                                    latency in front, no status read-back behind) */
 #define DOPF_F_STO_GENERAL 16384 /* storages: the general active-set body (kernels_agents.hip: sto_warm_body) also where the lean
-                                  * copper-plate body (sto_lean.h) applies — the two are compared by the tests */
+                                  * body (sto_lean.h: copper plates; networks with many storage blocks) applies — the two are
+                                  * compared by the tests */
 #define DOPF_F_NO_QUIET   32768 /* networks, single-GPU chain: always launch k_slack (never the "quiet" chain, in which the dual/price
                                   * kernel forms the node sums while no line is flagged); bitwise comparisons of the two chains */
 #define DOPF_F_XCHG_OWNER 65536 /* peer exchange: always the reduce-scatter + all-gather form (every chunk has an owner rank that adds the
@@ -243,7 +244,7 @@ typedef struct dopf_timing {
                                reduce_ms is an empty event pair */
     int32_t quiet;          /* 1 (networks): no line was flagged, k_slack was not launched (slack_ms is an empty event pair): the dual/price
                                kernel formed the node sums too */
-    int32_t sto_lean;       /* 1: the storages of this problem are solved by the lean copper-plate body (csrc/sto_lean.h) */
+    int32_t sto_lean;       /* 1: the storages of this problem are solved by the lean active-set body (csrc/sto_lean.h) */
     int32_t persist;        /* 1: dopf_iterate runs several iterations per launch on this context (DOPF_F_PERSIST; this timed call itself
                                launches iteration by iteration) */
 } dopf_timing;

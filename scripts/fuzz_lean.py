@@ -18,7 +18,7 @@ F_GENERAL = 16384
 worst_o, worst_g, bad, left_total = 0.0, 0.0, 0, 0
 t0 = time.time()
 for k in range(n_cases):
-    T = int(rng.choice([8, 16, 24, 24, 48, 96, 96]))
+    T = int(rng.choice([8, 16, 24, 24, 48, 96, 96, 5, 12, 20, 30, 36, 72, 120, 168]))       # full and ragged horizons, 8 to 64 lanes per storage
     G, S = int(rng.integers(5, 150)), int(rng.integers(3, 90))
     if rng.random() < 0.1:
         S = int(rng.integers(300, 1200))          # several storage items, more than one pass per block
