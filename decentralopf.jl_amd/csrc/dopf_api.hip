@@ -114,6 +114,9 @@ void make_items(const std::vector<int> &node_sorted, int N, int chunk, std::vect
 namespace dopf {
 
 // single: the single-GPU dopf_iterate path (nothing reads cons between the reduce and the dual step)
+// the quiet chain's dual/price kernel stages every partial row of its timestep in LDS: up to 96 KB of them
+static bool quiet_rows_fit(int rows) { return rows > 0 && (size_t)rows * sizeof(double) <= 96 * 1024; }
+
 static bool slice_dual(const DevView &v, bool single)
 {
     const size_t NT = (size_t)v.N * v.T, LT = (size_t)v.L * v.T;
@@ -421,7 +424,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     }
     std::vector<Item> gitems, sitems;
     int max_node_rows = 1;
-    std::vector<int> ngb, nsb, ngib, nsib;
+    std::vector<int> ngb, nsb, ngib, nsib, row_of_pos, pos_of_row;
     {
         const int R = v.genTT2 ? v.genR2 : v.genR;
         // ~2048 blocks fill the chip several times over; in the fused launch the generator blocks share the wave slots with
@@ -466,6 +469,28 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     for (int n = 0; n < N; ++n) v.maxNodeAgents = std::max(v.maxNodeAgents, (ngb[n + 1] - ngb[n]) + (nsb[n + 1] - nsb[n]));
     v.nGenItems = (int)gitems.size();
     v.nStoItems = (int)sitems.size();
+    if (L > 0) {
+        // rows of the transposed partial sums (DevView::part_T): node n owns rows [g0 + 2 s0, ...) — its generator items, then two per storage item
+        // (node order: generator item i -> i + 2 s0, storage item k -> g0' + 2 k and the row behind it; then placed by the writer's XCD)
+        v.rowsN = v.nGenItems + 2 * v.nStoItems;
+        std::vector<int> xcd((size_t)v.rowsN, 0), cnt(8, 0), beg(9, 0);
+        for (int i = 0; i < v.nGenItems; ++i) {
+            gitems[i].row = i + 2 * nsib[gitems[i].node];
+            xcd[(size_t)gitems[i].row] = ((v.fuseNet ? v.nStoItems : 0) + i) % 8;          // (k_net_agents: storage blocks in front)
+        }
+        for (int k = 0; k < v.nStoItems; ++k) {
+            sitems[k].row = ngib[sitems[k].node + 1] + 2 * k;
+            xcd[(size_t)sitems[k].row] = xcd[(size_t)sitems[k].row + 1] = k % 8;
+        }
+        for (int g = 0; g < v.rowsN; ++g) ++cnt[(size_t)xcd[(size_t)g]];
+        for (int x = 0; x < 8; ++x) beg[(size_t)x + 1] = beg[(size_t)x] + (cnt[(size_t)x] + 15) / 16 * 16;
+        v.rowsT = beg[8];
+        row_of_pos.assign((size_t)std::max(v.rowsT, 1), -1); pos_of_row.assign((size_t)std::max(v.rowsN, 1), 0);
+        std::vector<int> fillp(beg.begin(), beg.begin() + 8);
+        for (int g = 0; g < v.rowsN; ++g) { const int p_ = fillp[(size_t)xcd[(size_t)g]]++; row_of_pos[(size_t)p_] = g; pos_of_row[(size_t)g] = p_; }
+        for (int i = 0; i < v.nGenItems; ++i) gitems[i].row = pos_of_row[(size_t)gitems[i].row];
+        for (int k = 0; k < v.nStoItems; ++k) sitems[k].row = pos_of_row[(size_t)sitems[k].row];       // (the warm-start row: the next position)
+    }
     v.genBlocks = 0;
     if (v.fuseAgents && v.genChunk > 0 && !v.genSkip && v.genChunk <= kGenStreamRows * v.genR2 && !exp_env("DOPF_NO_GEN_STREAM")) {
         // as many generator blocks as find a wave slot next to the storage blocks (3 blocks of 256 per CU at the fused
@@ -554,6 +579,8 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
     TRY(dev_alloc(c, &v.part_ginj, (size_t)v.nGenItems * T)); TRY(dev_alloc(c, &v.part_gcost, v.nGenItems));
     TRY(dev_alloc(c, &v.part_sinj, (size_t)v.nStoItems * T)); TRY(dev_alloc(c, &v.part_scost, v.nStoItems));
     TRY(dev_alloc(c, &v.part_sinj_w, (size_t)v.nStoItems * T)); TRY(dev_alloc(c, &v.part_scost_w, v.nStoItems));
+    if (L > 0) { TRY(dev_upload(c, &v.row_of_pos, row_of_pos)); TRY(dev_upload(c, &v.pos_of_row, pos_of_row)); }
+    if (L > 0) TRY(dev_alloc(c, &v.part_T, (size_t)v.rowsT * T));      // (networks: the ADMM kernels' layout; the rows above serve dopf_central_solve)
     if (L > 0) TRY(dev_alloc(c, &v.prev_node, NT));
     TRY(dev_alloc(c, &v.nu_prev, (size_t)S * T)); TRY(dev_alloc(c, &v.nu_valid, S)); TRY(dev_alloc(c, &v.sto_fail, S));
     TRY(dev_alloc(c, &v.item_fail, v.nStoItems));
@@ -579,6 +606,12 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         if (L > 0 && L <= 256 && N <= 256 && n1 > kSmallConsensus && !v.splitDual && !exp_env("DOPF_TABLES_LAUNCH"))
             tw = (int)std::min<size_t>(8, (128 * 1024 - std::min<size_t>(own, 128 * 1024)) / per_wave);
         v.tablesInDual = tw;
+        {   // its dynamic LDS: q[N] | d[L] | G[L] | S[L] | the rows of its timestep (quiet chain), later the tables' scratch | sd[N] win[N] na[N]
+            const size_t scratch = (size_t)tw * (4 * (size_t)v.M2 + 1);
+            v.dualRowsOff = N + 3 * L;
+            v.dualSdOff = v.dualRowsOff + (int)std::max(scratch, (size_t)(quiet_rows_fit(v.rowsT) ? v.rowsN : 0));
+            v.dualLdsBytes = (int)(((size_t)v.dualSdOff + 3 * (size_t)N) * sizeof(double));
+        }
         // the same kernel forms the slack sums of its timestep (see DevView::slackInDual); DOPF_F_NO_TAIL_FUSE keeps the
         // k_reduce launch (the chain a sharded context runs: bitwise comparisons against it)
         v.slackDualOk = L > 0 && L <= 256 && N <= 256 && n1 > kSmallConsensus && !v.splitDual && !(q->flags & DOPF_F_NO_TAIL_FUSE) &&
@@ -586,7 +619,7 @@ int dopf_create(dopf_ctx **out, const dopf_problem *p, const dopf_params *q)
         // ... and, while no line is flagged, the node sums too (the quiet chain: no k_slack launch; DevView::quiet, dopf_iterate)
         // (up to 32 rows per node: one batch of the eight lanes' four loads. configs[3] at full size has 25 and is where the gain
         // ends — the node sums cost the dual kernel what k_slack and its boundary cost, 119.3 us per iteration either way)
-        c->quiet_ok = v.slackDualOk && !(q->flags & DOPF_F_KEEP_DELTAS) && (max_node_rows <= 32 || exp_env("DOPF_QUIET_ANY_SIZE")) &&
+        c->quiet_ok = v.slackDualOk && !(q->flags & DOPF_F_KEEP_DELTAS) && quiet_rows_fit(v.rowsT) &&
                       !(q->flags & DOPF_F_NO_QUIET);
         // the same chain on a peer exchange (k_slack stays: its node sums are what is exchanged): a function of the problem's shape and
         // the flags only — every rank decides alike

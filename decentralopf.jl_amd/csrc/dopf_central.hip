@@ -90,6 +90,7 @@ extern "C" int dopf_central_solve(const dopf_problem *p, const dopf_params *q, d
     DevView vred = v;                        // k_reduce without the slack-sum part: nodal sums and the cost only
     vred.L = 0;
     vred.sliceDual = 0;
+    vred.part_T = nullptr;                   // (kc_gen / kc_sto write partial rows, [row][t])
     vred.genRows = 0;                        // (kc_gen writes one partial row per item)
 
     std::vector<double> mg(v.nGenItems), ms(3 * (size_t)v.nStoItems), md(3 * (size_t)T);

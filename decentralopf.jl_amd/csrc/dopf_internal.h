@@ -33,7 +33,7 @@ inline const char *exp_env(const char *) { return nullptr; }
 
 // one block's share of the agent list: agents [a0, a1) all sit at `node`
 struct Item {
-    int a0, a1, node, pad;
+    int a0, a1, node, row;          // row (networks): the item's row in DevView::part_T (a storage item's scan partial; its warm-start partial: row + 1)
 };
 
 // device-resident status word block (one per context)
@@ -80,6 +80,17 @@ struct DevView {
     int genBlocks;                  // > 0 (needs genChunk): the fused launch has this many generator blocks, each walking items b, b + genBlocks, ...
     int debugLeave;                 // DOPF_F_DEBUG_LEAVE (tests)
     int coldInWarm;                 // networks: k_sto_warm calls the scan body itself for what it leaves over (no k_sto_update launch)
+    double *part_T;                 // networks (L > 0): the items' partial injection sums TRANSPOSED, [t][row] with rowsT rows per timestep — node by node
+    int rowsT;                      // (a node's generator items, then two rows per storage item: scan partial, warm-start partial). The block of the
+                                    // dual/price kernel that owns timestep t reads ALL rows of t as one contiguous vector (the quiet chain: no k_slack
+                                    // launch) instead of one 8-byte word out of every row of the [row][t] layout the copper plates keep (part_*inj);
+                                    // the sums are formed in the same order from either layout: same bits. Null: part_ginj / part_sinj / part_sinj_w.
+    int rowsN;                      // ... of which rowsN are items' rows: the rows are PLACED by the XCD their writer block runs on (block index mod 8,
+    const int *row_of_pos, *pos_of_row;   // eight regions on 128-byte boundaries) — written in node order, every 128-byte line of a timestep would collect 8-byte
+                                    // pieces in all eight L2s and be written back eight times at the kernel's end. row_of_pos[p]: the node-ordered row
+                                    // at position p (-1: padding); pos_of_row: its inverse. Item::row is a POSITION.
+    int dualRowsOff, dualSdOff;     // the one-launch dual/price kernel's dynamic LDS, in doubles: where the rows of its timestep (aliased with the tables'
+    int dualLdsBytes;               // scratch) and the vectors behind them start, and its size
     int tablesInDual;               // > 0 (networks on the one-launch dual/price kernel): that kernel builds the breakpoint tables of its
                                     // timestep itself, with this many waves; no k_tables launch
     int splitDual;                  // (experiments, DOPF_SPLIT_DUAL=1) networks: dual and price steps as two launches

@@ -320,7 +320,7 @@ __device__ __forceinline__ void gen_lines_body(const DevView &v, const int item,
         if (r == 0 && t < T) {
             double sum = 0.0;
             for (int q = 0; q < R; ++q) sum += red[q * TT + tt];
-            v.part_ginj[(size_t)item * T + t] = sum;
+            v.part_T[(size_t)t * v.rowsT + it.row] = sum;          // (networks: [t][row], read along the rows by the consensus kernels)
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
@@ -421,7 +421,7 @@ __device__ __forceinline__ void gen_lines_body2(const DevView &v, const int item
             if (tt < TT && t < T) {
                 double sum = 0.0;
                 for (int q = 0; q < R; ++q) sum += red[c][q * TT + tt];
-                v.part_ginj[(size_t)item * T + t] = sum;
+                v.part_T[(size_t)t * v.rowsT + it.row] = sum;
             }
         }
     }
@@ -1063,7 +1063,8 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
     if (item_fail < 0) item_fail = v.item_fail[blk];
     if (v.use_warm && item_fail == 0) {      // the warm start solved this whole item
         if (TAIL) return;                    // (nothing to add)
-        for (int t = tid; t < T; t += 256) v.part_sinj[(size_t)blk * T + t] = 0.0;
+        if (LINES) for (int t = tid; t < T; t += 256) v.part_T[(size_t)t * v.rowsT + it.row] = 0.0;
+        else for (int t = tid; t < T; t += 256) v.part_sinj[(size_t)blk * T + t] = 0.0;
         if (tid == 0) v.part_scost[blk] = 0.0;
         return;
     }
@@ -1362,6 +1363,7 @@ __device__ __forceinline__ void sto_cold_body(const DevView &v, const int blk, i
                 for (int g2 = 0; g2 < NG; ++g2) sum += red[(g2 * LPS + li) * NCH + c];
                 // (tail in the launch: this thread wrote the active-set body's sum of slot t itself, a moment ago)
                 if (TAIL) { const TailView tv = *v.tail; acc_add(tv, PERSIST ? ppar : v.st->tail_par, t, sum + v.part_sinj_w[(size_t)blk * T + t], tv.scaleInj); }
+                else if (LINES) v.part_T[(size_t)t * v.rowsT + it.row] = sum;
                 else v.part_sinj[(size_t)blk * T + t] = sum;
             }
         }
@@ -2137,6 +2139,7 @@ __device__ __forceinline__ int sto_warm_body(const DevView &v, const int blk, co
                 // tail in the launch: ONE counted add per block and slot. A block with storages left over for the scan body
                 // parks its sums in its partial row instead; the scan body (same block, same thread per slot) adds both.
                 if (TAIL && blockFail == 0) acc_add(tv, tpar, t, sum, tv.scaleInj);
+                else if (LINES) v.part_T[(size_t)t * v.rowsT + it.row + 1] = sum;
                 else v.part_sinj_w[(size_t)blk * T + t] = sum;
             }
         }
@@ -2182,7 +2185,8 @@ __global__ __launch_bounds__(256, DOPF_WARM_WAVES) void k_sto_warm(DevView v)
     if (left < 0) return;                                                               // halted
     if (LINES && v.coldInWarm) {
         if (left == 0) {                         // (what the scan body writes when there is nothing for it)
-            for (int t = threadIdx.x; t < v.T; t += 256) v.part_sinj[(size_t)blockIdx.x * v.T + t] = 0.0;
+            const int row = v.sto_items[blockIdx.x].row;
+            for (int t = threadIdx.x; t < v.T; t += 256) v.part_T[(size_t)t * v.rowsT + row] = 0.0;
             if (threadIdx.x == 0) v.part_scost[blockIdx.x] = 0.0;
         } else {
             sto_cold_lines_call<LPS, NCH>(v.self, blockIdx.x, left);
@@ -2221,7 +2225,8 @@ __global__ __launch_bounds__(256, DOPF_WARM_WAVES) void k_net_agents(DevView v)
                               : sto_warm_body<LPS, NCH, true>(v, si, v.st->halt);                  // ends on a __syncthreads
         if (left < 0) return;                                                           // halted
         if (left == 0) {                     // (what the scan body writes when there is nothing for it)
-            for (int t = threadIdx.x; t < v.T; t += 256) v.part_sinj[(size_t)si * v.T + t] = 0.0;
+            const int row = v.sto_items[si].row;
+            for (int t = threadIdx.x; t < v.T; t += 256) v.part_T[(size_t)t * v.rowsT + row] = 0.0;
             if (threadIdx.x == 0) v.part_scost[si] = 0.0;
         } else {
             sto_cold_lines_call<LPS, NCH>(v.self, si, left);

@@ -258,21 +258,32 @@ __device__ __forceinline__ double walk_sum(const DevView &v, const double *dtile
 // lane r of eight: rows i0 + r, i0 + r + 8, ... (below i1) of a node's partial rows at timestep t — generator items, then the
 // storage items' scan partials, then their warm-start partials. Four loads in flight, no branch between them (one select
 // on the address); the grouping is fixed (k_reduce level 1, and k_slack when it stores the node sums itself: same bits)
+// Networks keep the rows transposed (DevView::part_T, [t][row]: the node's rows side by side): where row jj of the node sits there
+__device__ __forceinline__ int row_pos(int jj, int ngi, int nsi)
+{
+    return jj < ngi ? jj : (jj < ngi + nsi ? ngi + 2 * (jj - ngi) : ngi + 2 * (jj - ngi - nsi) + 1);
+}
 __device__ __forceinline__ double rows_sum(const DevView &v, int g0, int ngi, int s0, int nsi, int i0, int i1, int r, int t)
 {
     constexpr int R = 8;
     const int T = v.T;
     double acc = 0.0;
+    const double *rowsT = v.part_T ? v.part_T + (size_t)t * v.rowsT : nullptr;      // (uniform choice)
+    const int base = g0 + 2 * s0;
     for (int i = i0 + r; i < i1; i += 4 * R) {
         double x[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = i + u * R;
             const int jj = j < i1 ? j : i0;                               // in range: always a valid row
-            const double *row = jj < ngi ? v.part_ginj + (size_t)(g0 + jj) * T
-                              : (jj < ngi + nsi ? v.part_sinj + (size_t)(s0 + jj - ngi) * T
-                                                : v.part_sinj_w + (size_t)(s0 + jj - ngi - nsi) * T);
-            const double val = row[t];
+            double val;
+            if (rowsT) val = rowsT[v.pos_of_row[base + row_pos(jj, ngi, nsi)]];
+            else {
+                const double *row = jj < ngi ? v.part_ginj + (size_t)(g0 + jj) * T
+                                  : (jj < ngi + nsi ? v.part_sinj + (size_t)(s0 + jj - ngi) * T
+                                                    : v.part_sinj_w + (size_t)(s0 + jj - ngi - nsi) * T);
+                val = row[t];
+            }
             x[u] = j < i1 ? val : 0.0;
         }
         acc += (x[0] + x[1]) + (x[2] + x[3]);
@@ -311,7 +322,10 @@ __global__ __launch_bounds__(256) void k_slack(DevView v, const int cap)
         const size_t at = (size_t)n + (size_t)N * (t < T ? t : 0);
         const double was = (r == 0 && t < T) ? v.prev_node[at] : 0.0;          // (on its way while the rows are read)
         const int g0 = v.node_gitem_beg[n], ngi = v.node_gitem_beg[n + 1] - g0, s0 = v.node_sitem_beg[n], nsi = v.node_sitem_beg[n + 1] - s0;
-        redn[tid] = t < T ? rows_sum(v, g0, ngi, s0, nsi, 0, ngi + 2 * nsi, r, t) : 0.0;
+        {   // (transposed rows: the eight row lanes of a timestep side by side in a wave — they read neighbouring words)
+            const int rr = v.part_T ? (tid & 7) : r, tr = v.part_T ? (tid >> 3) : tt;
+            redn[rr * 32 + tr] = t0 + tr < T ? rows_sum(v, g0, ngi, s0, nsi, 0, ngi + 2 * nsi, rr, t0 + tr) : 0.0;
+        }
         __syncthreads();
         if (r == 0 && t < T) {
             double sum = 0.0;
@@ -504,9 +518,10 @@ __global__ __launch_bounds__(256) void k_reduce(DevView v)
         const int ni = ngi + 2 * nsi;
         const int per = (ni + RB - 1) / RB;
         const int i0 = rb * per, i1 = min(ni, i0 + per);
-        const double acc = t < T ? rows_sum(v, g0, ngi, s0, nsi, i0, i1, r, t) : 0.0;
+        const int rr = v.part_T ? (tid & 7) : r, tr = v.part_T ? (tid >> 3) : tt;      // (transposed rows: see k_slack)
+        const double acc = tcx * TT + tr < T ? rows_sum(v, g0, ngi, s0, nsi, i0, i1, rr, tcx * TT + tr) : 0.0;
         if (halt) return;                                   // (uniform)
-        red[tid] = acc;
+        red[rr * TT + tr] = acc;
         __syncthreads();
         const bool direct = RB == 1 && !v.sliceDual;       // one slice per node: its sum IS the node's sum
         if (r == 0 && t < T) {
@@ -1151,7 +1166,7 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
 #ifdef DOPF_DUAL_STAMPS          // (measurement build: wall-clock stamps of block T/2's phases in the status block's counters, scripts/dual_stamps.py)
     if (UPDATE && threadIdx.x == 0 && (int)blockIdx.x == v.T / 2) v.st->dbg_reason[0] = wall_clock64();
 #endif
-    extern __shared__ double sh[];               // q[N] injections | d[L] mu - rho | G[L] | S[L]
+    extern __shared__ double sh[];               // q[N] injections | d[L] mu - rho | G[L] | S[L] | rows of t (later: table scratch) | slack vectors
     __shared__ double red[3][1024];
     __shared__ double wsum[4], wmx[2][4];
     __shared__ int wany[4], wnz[4], lastBlock;
@@ -1166,7 +1181,7 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
     // SID: the slack sums of this timestep's lines are formed HERE, from the PTDF rows the flows need anyway and the nodes'
     // injection changes (k_slack) — with k_reduce's arithmetic, part by part — instead of by a launch in between
     constexpr bool sid = UPDATE && SID;
-    double *sdL = sh + N + 3 * L + (size_t)v.tablesInDual * (4 * v.M2 + 1), *winL = sdL + N, *naL = winL + N;
+    double *sdL = sh + v.dualSdOff, *winL = sdL + N, *naL = winL + N;
     const int pl = tid >> 8, l = tid & 255;
     const bool lt = pl == 0 && l < L;
     const size_t i = (size_t)(l < L ? l : 0) + (size_t)L * t;
@@ -1193,19 +1208,50 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
     const double lam_old = v.lam[t], s_old = v.s[t];
     double x = 0.0, cost_q = 0.0;
     if (QUIET) {
-        // node sums of timestep t: thread (node, lane r of eight), rows r, r + 8, ... of the node (rows_sum: k_slack's order),
-        // the eight lanes added in lane order; 128 nodes per pass
+        // Node sums of timestep t. The items' partial sums are kept transposed (DevView::part_T): ALL rows of t are one contiguous
+        // vector — brought into LDS by coalesced loads that depend on nothing (the node tables load beside them), instead of one
+        // 8-byte word out of every row behind the tables' round trip (76 KB of sectors per block on the 118-node share). Then
+        // thread (node, lane r of eight) adds rows r, r + 8, ... of its node from LDS, the eight lanes are added in lane order:
+        // rows_sum's grouping, k_slack's bits.
+        double *rowsL = sh + v.dualRowsOff;
+        const double *src = v.part_T + (size_t)t * v.rowsT;
+        double xr[4];                                    // four loads in flight per lane: the first 4 096 rows
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int j = tid + 1024 * u; xr[u] = j < v.rowsT ? src[j] : 0.0; }
+        int gr[4];                                       // (where the position's row sits in node order: the rows are placed by writer XCD)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int j = tid + 1024 * u; gr[u] = j < v.rowsT ? v.row_of_pos[j] : -1; }
         for (int nb = 0; nb < N; nb += 128) {
             const int n = nb + (tid >> 3), r = tid & 7;
             double acc = 0.0, was = 0.0, dem = 0.0;
-            if (n < N) {
-                const int g0 = v.node_gitem_beg[n], ngi = v.node_gitem_beg[n + 1] - g0, s0 = v.node_sitem_beg[n], nsi = v.node_sitem_beg[n + 1] - s0;
+            int base = 0, ngi = 0, nsi = 0;
+            if (n < N) {                                 // (the node tables: beside the rows, not in front of them)
+                const int g0 = v.node_gitem_beg[n], s0 = v.node_sitem_beg[n];
+                ngi = v.node_gitem_beg[n + 1] - g0; nsi = v.node_sitem_beg[n + 1] - s0; base = g0 + 2 * s0;
                 if (r == 0) { was = v.prev_node[n + (size_t)N * t]; dem = v.demand[n + (size_t)N * t]; }
-                acc = rows_sum(v, g0, ngi, s0, nsi, 0, ngi + 2 * nsi, r, t);
+            }
+            if (nb == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (gr[u] >= 0) rowsL[gr[u]] = xr[u];
+                for (int j = 4096 + tid; j < v.rowsT; j += 1024) { const int g_ = v.row_of_pos[j]; if (g_ >= 0) rowsL[g_] = src[j]; }
+            }
+            if (halt) return;                            // (uniform; nothing has been stored)
+            // (everything in flight is a load; the stores come behind the kernel's barriers, which wait for LDS only — see below)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (n < N) {
+                const int i1 = ngi + 2 * nsi;
+                for (int i = r; i < i1; i += 32) {
+                    double x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = i + 8 * u;
+                        x[u] = j < i1 ? rowsL[base + row_pos(j, ngi, nsi)] : 0.0;
+                    }
+                    acc += (x[0] + x[1]) + (x[2] + x[3]);
+                }
             }
             red[0][tid] = acc;
-            __syncthreads();
-            if (halt) return;                            // (uniform; nothing has been stored)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (n < N && r == 0) {
                 double sn = 0.0;
                 for (int k = 0; k < 8; ++k) sn += red[0][tid + k];
@@ -1214,7 +1260,7 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
                 q[n] = sn - dem;                                             // results.jl:58-100
                 v.prev_node[at] = sn; v.node_dsum[at] = sn - was; v.cons[at] = sn;
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         if (t == 0) {                                    // the cost, by the block of the first timestep (k_slack's order)
             const int ngr = v.genRows > 0 ? v.genRows : v.nGenItems, nc = ngr + v.nStoItems;
@@ -1230,15 +1276,17 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
 #pragma unroll
                     for (int u = 0; u < 8; ++u) c += k0 + 256 * u < nc ? xc[u] : 0.0;
                 }
+            // (block_sum256's tree — lanes i, i + 128, then + 64, ... + 1 — with barriers that wait for LDS only: the two levels that
+            // cross waves through LDS, the six inside wave 0 by shuffles; same operands at every level, same bits)
             if (tid < 256) red[0][tid] = c;
-            __syncthreads();
-            for (int sft = 128; sft > 0; sft >>= 1) {
-                if (tid < sft) red[0][tid] += red[0][tid + sft];
-                __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (tid < 64) {
+                double cs = (red[0][tid] + red[0][tid + 128]) + (red[0][tid + 64] + red[0][tid + 192]);
+                for (int d = 32; d > 0; d >>= 1) cs += __shfl_xor(cs, d);
+                if (tid == 0) { wmx[0][0] = cs; v.cons[NT + 2 * LT] = cs; }
             }
-            cost_q = red[0][0];
-            __syncthreads();
-            if (tid == 0) v.cons[NT + 2 * LT] = cost_q;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            cost_q = wmx[0][0];
         }
         if (tid < N) x = q[tid];
     } else if (tid < N) {
@@ -1253,7 +1301,12 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         for (int d = 32; d > 0; d >>= 1) ps += __shfl_xor(ps, d);
         if (lane == 0 && tid < 256) wsum[tid >> 6] = ps;
     }
-    const int anyWalk = (sid && !QUIET) ? __syncthreads_or(wf) : (__syncthreads(), 0);
+    // (only LDS data crosses this kernel's barriers, and what a later phase loads it waits for itself: the barriers wait for LDS
+    // alone — __syncthreads() also waits for the acknowledgement of every store issued so far)
+#define DOPF_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    int anyWalk = 0;
+    if (sid && !QUIET) anyWalk = __syncthreads_or(wf);
+    else DOPF_LDS_BARRIER();
 
 #ifdef DOPF_DUAL_STAMPS
     if (UPDATE && tid == 0 && t == T / 2) v.st->dbg_reason[1] = wall_clock64();
@@ -1322,7 +1375,7 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         }
         red[1][tid] = pu; red[2][tid] = pk;
     }
-    __syncthreads();
+    DOPF_LDS_BARRIER();
 
 #ifdef DOPF_DUAL_STAMPS
     if (UPDATE && tid == 0 && t == T / 2) v.st->dbg_reason[3] = wall_clock64();
@@ -1364,7 +1417,7 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         for (int d = 32; d > 0; d >>= 1) { rm = fmax(rm, __shfl_xor(rm, d)); rr = fmax(rr, __shfl_xor(rr, d)); }
         if (lane == 0) { wany[tid >> 6] = a; wnz[tid >> 6] = z; wmx[0][tid >> 6] = rm; wmx[1][tid >> 6] = rr; }
     }
-    __syncthreads();
+    DOPF_LDS_BARRIER();
     const int anyNeed = wany[0] | wany[1] | wany[2] | wany[3];
     const int nz = wnz[0] | wnz[1] | wnz[2] | wnz[3];
     const bool lin = !anyNeed;
@@ -1431,7 +1484,7 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         tk_ = atomicAdd(v.dual_ticket + zero, 1ull | (viol_ << 32) | ((unsigned long long)(anyNeed ? 1 : 0) << 48));
     }
     red[0][tid] = pr; red[1][tid] = psx; red[2][tid] = sl;
-    __syncthreads();
+    DOPF_LDS_BARRIER();
 
 #ifdef DOPF_DUAL_STAMPS
     if (UPDATE && tid == 0 && t == T / 2) v.st->dbg_cyc[2] = wall_clock64();
@@ -1455,7 +1508,7 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         // (k_tables) that in the settled state finds nothing to do: 5 us + a kernel boundary per iteration.
         __syncthreads();                             // this block's stores above are visible to all its waves
         const int TW = v.tablesInDual, wv = tid >> 6;
-        double *tsh = sh + N + 3 * L + (size_t)wv * (4 * v.M2 + 1);
+        double *tsh = sh + v.dualRowsOff + (size_t)wv * (4 * v.M2 + 1);
         if (wv < TW)
             for (int nn = wv; nn < N; nn += TW) build_table(v, nn, t, tsh);
     }
@@ -1492,6 +1545,8 @@ __global__ __launch_bounds__(1024) void k_dual_price_t1024(DevView v)
         }
     }
 }
+
+#undef DOPF_LDS_BARRIER
 
 // dual step + prices + stop test in ONE block when the consensus state is small (every copper-plate case):
 // saves a launch per iteration, which is what the small configurations are bound by
@@ -1696,10 +1751,10 @@ __global__ __launch_bounds__(256) void k_dual_price_small(DevView v, XchgView x)
     }
 }
 
-// dynamic LDS of k_dual_price_t1024: its own vectors, plus table scratch for tablesInDual waves
+// dynamic LDS of k_dual_price_t1024: its own vectors, plus table scratch for tablesInDual waves / the rows of its timestep (dopf_create)
 static size_t t1024_lds(const DevView &v)
 {
-    const size_t bytes = (4 * (size_t)v.N + 3 * (size_t)v.L + (size_t)v.tablesInDual * (4 * (size_t)v.M2 + 1)) * sizeof(double);
+    const size_t bytes = (size_t)v.dualLdsBytes;
     static std::atomic<unsigned long long> raised{0ull};
     if (bytes > 48 * 1024 && first_time_on_this_device(raised)) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(k_dual_price_t1024<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);

@@ -795,6 +795,7 @@ __device__ __forceinline__ int sto_lean_body(const DevView &v, const int blk, co
             if (!LZ_IN(c)) continue;
             const double sum = ((wsumS[0][t] + wsumS[1][t]) + wsumS[2][t]) + wsumS[3][t];
             if (TAIL && blockFail == 0) acc_add(tv, tpar, t, sum, tv.scaleInj);
+            else if (LINES) pf->part_T[(size_t)t * pf->rowsT + it.row + 1] = sum;
             else pf->part_sinj_w[(size_t)blk * T + t] = sum;
         }
     }

@@ -7,12 +7,13 @@ dopf_pkg.load()
 from decentralopf_jl_amd import _capi, synth
 import bench
 _capi._pin_hip_runtime()
-api = _capi.CApi("scripts/tmp/libdopf_dstamps.so", "dopf_")
+api = _capi.CApi(os.environ.get("DOPF_STAMPS_LIB", "scripts/tmp/libdopf_dstamps.so"), "dopf_")
 names = ["entry", "first barrier (sums, demand, line state in)", "flow + slack dot products", "barrier", "line update, barriers", "price dot products",
          "barrier", "price stores", "ticket back"]
 for wl in sys.argv[1:] or ["config3-share"]:
-    pp = bench.make_problem(synth, wl); A = pp.G + pp.S
-    e = _capi.Engine(api, params=_capi.default_params(gamma=1.0 / A, w_flow=0.3 / A, eps=0.0), **pp.engine_kwargs())
+    pp = synth.baseline_config(3, scale=float(os.environ["DOPF_STAMPS_SCALE"])) if os.environ.get("DOPF_STAMPS_SCALE") else bench.make_problem(synth, wl)
+    A = pp.G + pp.S
+    e = _capi.Engine(api, params=_capi.default_params(gamma=1.0 / A, w_flow=0.3 / A, eps=0.0, flags=int(os.environ.get("DOPF_STAMPS_FLAGS", "0"))), **pp.engine_kwargs())
     e.iterate(300)
     acc = np.zeros(9)
     n = 50
