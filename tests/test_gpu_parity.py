@@ -486,6 +486,8 @@ SLACK_IN_DUAL = [
     ("30 nodes / 45 lines, literal flow weight", lambda: synth.synthetic_case(500, 50, 168, N=30, L=45, seed=12), None),
     ("118 nodes / 186 lines (2 % of configs[3])", lambda: synth.baseline_config(3, scale=0.02), 0.3),
     ("118 nodes / 186 lines, literal flow weight", lambda: synth.baseline_config(3, scale=0.02), None),
+    # more than 32 partial rows per node (the quiet chain's old limit): the dual/price kernel stages ~1 100 rows per timestep in LDS
+    ("30 nodes / 45 lines, 40 rows per node", lambda: synth.synthetic_case(3000, 300, 96, N=30, L=45, seed=13, fmax_factor=1.0, fmax_min=20), 0.3),
 ]
 
 
