@@ -538,21 +538,29 @@ def test_hip_slack_sums_in_the_dual_launch_are_bit_identical(hip_api, monkeypatc
         assert qa[1] == 1
 
 
-def test_hip_row_skipping_is_bit_identical(hip_api):
-    """1M agents x 24: the generator kernel that skips rows of P parked on a bound against the full sweep."""
-    pp = synth.baseline_config(4)
+@pytest.mark.parametrize("idx,steps", [(4, (1, 7, 60)), (2, (1, 2, 3, 9, 25, 110)), (1, (1, 5, 40, 90))],
+                         ids=["config4: the generator launch", "config2: streaming generator blocks of the one-launch iteration", "config1"])
+def test_hip_row_skipping_is_bit_identical(hip_api, idx, steps):
+    """The generator sweeps that skip rows of P parked on a bound against the full sweep: 1M agents x 24 (a launch of its own,
+    gen_pair_skip_body) and the streaming generator blocks of the one-launch iteration (config2, config1: gen_pair_stream_skip) —
+    every array the ABI exposes, bit for bit, through the cold start and after; and the state words hold what P holds."""
+    pp = synth.baseline_config(idx)
     g = 1.0 / (pp.G + pp.S)
     a = make_engine(hip_api, pp, eps=0.0, gamma=g)
     b = make_engine(hip_api, pp, eps=0.0, gamma=g, flags=_capi.F_NO_ROW_SKIP)
-    for n in (1, 7, 60):
+    for n in steps:
         a.iterate(n)
         b.iterate(n)
-        Pa, Pb = a.get_primal()[0], b.get_primal()[0]
-        assert np.array_equal(Pa, Pb)
-        assert np.array_equal(a.get_duals()[0], b.get_duals()[0])
+        sa, sb = state_of(a), state_of(b)
+        for k in sa:
+            if sa[k].size:
+                assert np.array_equal(sa[k], sb[k]), (n, k)
         assert a.get_consensus()[4] == b.get_consensus()[4]
+        assert a.get_residuals() == b.get_residuals()
+    Pa = a.get_primal()[0]
     sat = ((Pa == 0).all(axis=1) | (Pa == pp.gen_pmax[:, None]).all(axis=1)).mean()
     assert sat > 0.3            # the skipping path really had rows to skip
+    assert a.solver_failures() == 0 and b.solver_failures() == 0
 
 
 def test_hip_config2_time_to_residual_and_optimum(hip_api):
