@@ -60,6 +60,8 @@ for k in range(n_cases):
     if h.solver_failures():
         bad += 1
         print("SOLVER FAILURES", case, params, h.solver_failures(), flush=True)
+    if max(w_o, w_g) > float(os.environ.get("FUZZ_REPORT", "1e-7")):
+        print("LARGE", case, params, "flags", flags, "shape", shape, "iterations", iters, "vs oracle %.2e vs general body %.2e" % (w_o, w_g), "left", left_total, flush=True)
     worst_o, worst_g = max(worst_o, w_o), max(worst_g, w_g)
     h.close(); g.close(); o.close()
     if k % 10 == 9:
